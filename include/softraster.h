@@ -1,0 +1,151 @@
+/*
+ * softraster.h -- C ABI of the MI355X (gfx950) compute rasteriser that stands behind the draw path
+ * of LesleyLai/Vulkan-Renderer.
+ *
+ * The reference has no plugin or FFI interface; the seam is its own host API.  Each entry point
+ * below names the reference call site it replaces (paths relative to the reference root).  All
+ * functions return SR_OK (0) or a negative sr_status; nothing throws or aborts across this boundary
+ * (the reference's own convention, beyond::expected<T,VkResult> in src/vulkan_helper/buffer.hpp:84-90
+ * and VKH_CHECK/panic in src/vulkan_helper/check.hpp:8-15, can be rebuilt on top: see the C++ shim).
+ *
+ * Threading: like the reference (one host thread, src/main.cpp:163-171) calls on one device handle
+ * are not thread-safe.  Every handle owns one HIP stream; sr_draw is asynchronous on it,
+ * read-backs synchronise.
+ */
+#ifndef SOFTRASTER_H
+#define SOFTRASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_API __attribute__((visibility("default")))
+
+typedef enum sr_status {
+    SR_OK = 0,
+    SR_ERR_INVALID_ARGUMENT = -1,
+    SR_ERR_OUT_OF_MEMORY = -2,
+    SR_ERR_DEVICE = -3,         /* a HIP call failed; sr_last_error_string() has the HIP message */
+    SR_ERR_INDEX_OUT_OF_RANGE = -4,
+    SR_ERR_UNSUPPORTED = -5,
+    SR_ERR_NO_DEVICE = -6       /* no gfx950 device visible: the library never falls back to the CPU */
+} sr_status;
+
+typedef struct sr_device_t* sr_device;
+typedef struct sr_mesh_t* sr_mesh;
+typedef struct sr_texture_t* sr_texture;
+typedef struct sr_target_t* sr_target;
+
+/* Sampler state; sr_sampler_default() returns the one src/texture.cpp:246-263 creates. */
+typedef struct sr_sampler_desc {
+    float min_lod;        /* 0 */
+    float max_lod;        /* (float)mip_levels; a negative value means "use mip_levels" */
+    float mip_lod_bias;   /* 0 */
+    float max_anisotropy; /* 16; recorded, the filter footprint stays isotropic */
+} sr_sampler_desc;
+
+typedef struct sr_rect { int32_t x, y, width, height; } sr_rect;
+
+/* What sr_target_readback returns. */
+typedef enum sr_readback_kind {
+    SR_READ_COLOR_BGRA8 = 0, /* height*width*4 bytes, B,G,R,A: the swap-chain format, src/vulkan_helper/swapchain.cpp:17-21 */
+    SR_READ_DEPTH_F32 = 1,   /* height*width*samples floats; 1.0 where nothing was drawn (clear, src/main.cpp:921) */
+    SR_READ_TRI_ID_U32 = 2,  /* height*width*samples; 0xFFFFFFFF where nothing was drawn */
+    SR_READ_VIS_U64 = 3      /* height*width*samples; (depth bits << 32) | triangle id */
+} sr_readback_kind;
+
+/* Work counters of the last sr_draw on a target (all views summed). */
+typedef struct sr_draw_stats {
+    uint64_t vertices;            /* V: vertices transformed */
+    uint64_t triangles;           /* T: triangles submitted */
+    uint64_t triangles_binned;    /* front-facing triangles that cover at least one tile */
+    uint64_t tile_refs;           /* R: (triangle, tile) references emitted */
+    uint64_t triangles_unprojectable; /* dropped: a vertex at w <= 0 or outside the guard band */
+    uint64_t shaded_pixels;       /* Pv: pixels with at least one covered sample */
+    uint64_t visible_triangles;   /* F: distinct triangles owning at least one sample */
+    uint64_t pixels;              /* P: pixels of the stored rectangle */
+} sr_draw_stats;
+
+/* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */
+typedef struct sr_stage_times {
+    float vertex_ms, setup_ms, scan_ms, fill_ms, raster_ms, fragment_ms, total_ms;
+} sr_stage_times;
+
+/* ---- device: replaces vkh::GPUDevice, src/vulkan_helper/gpu_device.hpp:42-48 (constructed at
+ * src/main.cpp:144).  Fails with SR_ERR_NO_DEVICE when the ordinal is not a gfx950 GPU. */
+SR_API int sr_device_create(int hip_ordinal, sr_device* out);
+SR_API int sr_device_destroy(sr_device dev);
+/* vkDeviceWaitIdle, src/main.cpp:170 */
+SR_API int sr_device_synchronize(sr_device dev);
+SR_API const char* sr_status_string(int status);
+SR_API const char* sr_last_error_string(void);
+
+/* ---- mesh: replaces create_mesh_from_data, src/mesh.hpp:69-72 / src/mesh.cpp:79-87.
+ * vertices: n_vertices records of the reference's Vertex (32 bytes: pos f32x3, normal f32x3,
+ * uv f32x2; src/mesh.hpp:18-54).  indices: uint32 triangle list (src/main.cpp:561, 947-948).
+ * Data is fully uploaded on return, as with the reference's blocking staging copies. */
+SR_API int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices,
+                          const uint32_t* indices, uint32_t n_indices, sr_mesh* out);
+SR_API int sr_mesh_destroy(sr_device dev, sr_mesh mesh);
+
+/* ---- texture: replaces create_texture / destroy_texture, src/texture.hpp:17-24.
+ * rgba8: width*height*4 bytes interpreted as VK_FORMAT_R8G8B8A8_SRGB (src/texture.cpp:209).
+ * Builds floor(log2(max(w,h)))+1 levels in device memory by successive linear blits
+ * (src/texture.cpp:87-176).  sampler == NULL selects sr_sampler_default(). */
+SR_API void sr_sampler_default(sr_sampler_desc* out);
+SR_API int sr_texture_create_rgba8_srgb(sr_device dev, const void* rgba8, int width, int height,
+                                        const sr_sampler_desc* sampler, sr_texture* out);
+SR_API int sr_texture_destroy(sr_device dev, sr_texture tex);
+SR_API int sr_texture_mip_levels(sr_texture tex);
+/* copies one level (RGBA8, max(1,w>>level) * max(1,h>>level) * 4 bytes) to the host; no reference
+ * counterpart (the reference never reads an image back); used to check the mip chain */
+SR_API int sr_texture_read_level(sr_device dev, sr_texture tex, int level, void* host_rgba8, size_t bytes);
+
+/* ---- render target: replaces the swap-chain colour image, the multisampled colour and depth
+ * attachments and the clear values (src/main.cpp:377-431, 723-738, 919-921).
+ * width/height: frame size used by the viewport transform.  samples: 1 or 4 (the reference takes
+ * the device maximum, src/vulkan_helper/gpu_device.cpp:16-30).  n_views: layers drawn by one
+ * sr_draw.  rect: the part of the frame this target stores and rasterises (NULL = whole frame);
+ * used to split one frame over several GPUs by screen region. */
+SR_API int sr_target_create(sr_device dev, int width, int height, int samples, uint32_t n_views,
+                            const sr_rect* rect, sr_target* out);
+SR_API int sr_target_destroy(sr_device dev, sr_target target);
+/* Render colour into caller-owned device memory (n_views * rect.height * rect.width * 4 bytes)
+ * instead of the target's own buffer, e.g. a tensor handed to a collective.  NULL restores it. */
+SR_API int sr_target_bind_color(sr_device dev, sr_target target, void* device_ptr);
+/* No reference counterpart (the reference only presents): copy one view's result to the host. */
+SR_API int sr_target_readback(sr_device dev, sr_target target, int kind, uint32_t view,
+                              void* host, size_t bytes);
+
+/* ---- draw: replaces update_uniform_buffer + the recorded render pass + vkQueueSubmit
+ * (src/main.cpp:988-1004, 897-959, 1051): clear, vertex shader, triangle setup and binning,
+ * rasterisation with depth test LESS, fragment shader, sRGB store, multisample resolve.
+ * ubo_blocks: n_views uniform blocks of ubo_stride bytes each (>= 204; 208 for std140), laid out
+ * as the reference's UniformBufferObject (src/main.cpp:50-55): model, view, proj column-major
+ * mat4 at 0/64/128, camera_pos vec3 at 192.  Host memory; it is consumed before the call returns.
+ * textures: albedo, normal, metallic, roughness in the binding order of src/main.cpp:461-516
+ * (the normal map is bound but never sampled, shaders/shader.frag:35-52; it may be NULL).
+ * Draws the whole index buffer as one instance (vkCmdDrawIndexed(indices_size,1,0,0,0),
+ * src/main.cpp:954).  Asynchronous. */
+SR_API int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_blocks,
+                   uint32_t n_views, size_t ubo_stride, const sr_texture textures[4]);
+
+/* ---- instrumentation (no reference counterpart) */
+SR_API int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out);
+/* When enabled, sr_draw brackets every stage with HIP events on the device's stream. */
+SR_API int sr_profile_enable(sr_device dev, int enabled);
+SR_API int sr_profile_get(sr_device dev, sr_stage_times* out);
+/* Per-vertex results of the vertex stage for one uniform block, for parity checks:
+ * clip_out: n_vertices*4 floats (gl_Position); screen_out: n_vertices*16 bytes
+ * {int32 x_fixed, int32 y_fixed, float depth, float inv_w}, inv_w == 0 for unprojectable vertices.
+ * Either may be NULL. */
+SR_API int sr_debug_vertex_stage(sr_device dev, sr_mesh mesh, const void* ubo_block, int width,
+                                 int height, float* clip_out, void* screen_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFTRASTER_H */

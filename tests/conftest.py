@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "vulkan-renderer_amd"), os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def sr():
+    import softraster
+    return softraster
+
+
+@pytest.fixture(scope="session")
+def device(sr):
+    """One device handle for the whole GPU session.  No fallback: if the HIP library or the GPU is
+    missing this raises, and the gpu-marked tests fail loudly."""
+    dev = sr.Device(0)
+    yield dev
+    dev.close()

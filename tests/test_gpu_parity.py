@@ -1,0 +1,168 @@
+"""Parity of the HIP draw path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar: clip coordinates, window-space vertex records, coverage, depth and triangle ids are bit-exact;
+colour is within 1 LSB per 8-bit channel on >= 99.9 % of the pixels (the oracle uses libm powf/log2f,
+the kernels use the GPU's exp2/log2 instructions)."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+COLOR_TOL_LSB = 1
+COLOR_MIN_FRACTION = 0.999
+
+
+def _check_view(got, ref, check_color=True):
+    util.assert_visibility_equal(got, ref)
+    if check_color:
+        frac, worst = util.color_match_fraction(got["bgra"], ref["bgra"], COLOR_TOL_LSB)
+        assert frac >= COLOR_MIN_FRACTION, f"colour within {COLOR_TOL_LSB} LSB on {frac:.5f} of pixels (worst {worst})"
+
+
+@pytest.mark.parametrize("segments", [32, 88])
+def test_vertex_stage_bit_exact(sr, oracle, device, segments):
+    verts, idx = sr.scene.uv_sphere(segments, segments)
+    ubo = sr.scene.default_camera_ubo(800, 600)
+    mesh = sr.create_mesh_from_data(device, verts, idx)
+    clip, screen = mesh.vertex_stage(ubo, 800, 600)
+    mesh.destroy()
+    rclip, rscreen = oracle.vertex_stage(ubo, verts, 800, 600)
+    assert np.array_equal(clip.view(np.uint32), rclip.view(np.uint32))
+    assert np.array_equal(screen.view(np.uint8), rscreen.view(np.uint8))
+
+
+def test_vertex_stage_general_matrices_and_unprojectable(sr, oracle, device):
+    rng = np.random.default_rng(3)
+    verts = np.zeros((5000, 8), np.float32)
+    verts[:, :3] = rng.uniform(-6, 6, size=(5000, 3))
+    model = np.eye(4, dtype=np.float32)
+    model[:3, :3] = rng.normal(size=(3, 3)).astype(np.float32)
+    model[:3, 3] = (0.3, -0.2, 0.1)
+    ubo = sr.scene.default_camera_ubo(1920, 1080, model=model)
+    mesh = sr.create_mesh_from_data(device, verts, np.zeros(0, np.uint32))
+    clip, screen = mesh.vertex_stage(ubo, 1920, 1080)
+    mesh.destroy()
+    rclip, rscreen = oracle.vertex_stage(ubo, verts, 1920, 1080)
+    assert (rscreen["rw"] == 0).sum() > 10, "the test must contain vertices behind the eye"
+    assert np.array_equal(clip.view(np.uint32), rclip.view(np.uint32))
+    assert np.array_equal(screen.view(np.uint8), rscreen.view(np.uint8))
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+@pytest.mark.parametrize("segments", [32, 88])
+def test_reference_frame_800x600(sr, oracle, device, segments, samples):
+    """BASELINE config 1: one 800x600 frame of the bundled-model stand-in with the default camera."""
+    verts, idx = sr.scene.uv_sphere(segments, segments)
+    ubo = sr.scene.default_camera_ubo(800, 600)
+    images = sr.scene.material_textures(256)
+    got = util.gpu_render(sr, device, verts, idx, images, ubo, 800, 600, samples)[0]
+    ref = oracle.draw(ubo, verts, idx, images, 800, 600, samples, threads=8)
+    _check_view(got, ref)
+    assert got["stats"]["shaded_pixels"] == ref["stats"]["shaded_px"]
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_triangle_soup_large_and_small_with_ties(sr, oracle, device, samples):
+    verts, idx = util.random_soup(6000, seed=11, size=0.8)
+    ubo = sr.scene.default_camera_ubo(640, 360)
+    images = sr.scene.material_textures(64, seed=5)
+    got = util.gpu_render(sr, device, verts, idx, images, ubo, 640, 360, samples)[0]
+    ref = oracle.draw(ubo, verts, idx, images, 640, 360, samples, threads=8)
+    _check_view(got, ref)
+
+
+def test_huge_triangles_cover_many_tiles(sr, oracle, device):
+    verts, idx = sr.scene.screen_quad(z=0.0, half=30.0, uv_scale=40.0)
+    ubo = sr.scene.default_camera_ubo(1920, 1080)
+    images = sr.scene.material_textures(128)
+    got = util.gpu_render(sr, device, verts, idx, images, ubo, 1920, 1080, 1)[0]
+    ref = oracle.draw(ubo, verts, idx, images, 1920, 1080, 1, threads=8)
+    _check_view(got, ref)
+
+
+def test_near_plane_crossing_is_dropped_and_counted(sr, oracle, device):
+    verts, idx = sr.scene.screen_quad(z=0.0, half=500.0)   # reaches behind the eye
+    small, sidx = sr.scene.uv_sphere(16, 16)
+    v = np.concatenate([verts, small]); i = np.concatenate([idx, sidx + 4]).astype(np.uint32)
+    ubo = sr.scene.default_camera_ubo(320, 240)
+    images = sr.scene.material_textures(32)
+    got = util.gpu_render(sr, device, v, i, images, ubo, 320, 240, 1)[0]
+    ref = oracle.draw(ubo, v, i, images, 320, 240, 1)
+    _check_view(got, ref)
+    assert ref["stats"]["tris_clip_culled"] == 2
+    assert got["stats"]["triangles_unprojectable"] == 2
+
+
+def test_empty_mesh_and_offscreen_mesh(sr, oracle, device):
+    images = sr.scene.material_textures(16)
+    ubo = sr.scene.default_camera_ubo(128, 96)
+    got = util.gpu_render(sr, device, np.zeros((0, 8), np.float32), np.zeros(0, np.uint32), images, ubo, 128, 96, 1)[0]
+    assert (got["tri"] == sr.NO_TRIANGLE).all() and (got["depth"] == 1.0).all()
+    assert (got["bgra"] == np.array([0, 0, 0, 255], np.uint8)).all()
+    verts, idx = sr.scene.uv_sphere(8, 8)
+    verts[:, 0] += 50.0
+    got = util.gpu_render(sr, device, verts, idx, images, ubo, 128, 96, 1)[0]
+    assert (got["tri"] == sr.NO_TRIANGLE).all()
+
+
+def test_multi_view_batch_matches_single_views(sr, oracle, device):
+    """BASELINE config 2 in small: a batch of orbit cameras drawn by one call."""
+    verts, idx = sr.scene.uv_sphere(32, 32)
+    ubos = sr.scene.orbit_ubos(6, 480, 270)
+    images = sr.scene.material_textures(128)
+    got = util.gpu_render(sr, device, verts, idx, images, ubos, 480, 270, 1)
+    for k in range(6):
+        ref = oracle.draw(ubos[k], verts, idx, images, 480, 270, 1, threads=4)
+        _check_view(got[k], ref)
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_screen_split_is_partition_independent(sr, oracle, device, samples):
+    """Sort-first building block: a target restricted to a rectangle stores exactly the crop of the
+    full frame, for rectangles that cut through tiles and pixels quads."""
+    verts, idx = sr.scene.uv_sphere(64, 48)
+    ubo = sr.scene.default_camera_ubo(640, 480)
+    images = sr.scene.material_textures(128)
+    full = util.gpu_render(sr, device, verts, idx, images, ubo, 640, 480, samples)[0]
+    for rect in [(0, 0, 640, 240), (0, 240, 640, 240), (100, 51, 333, 207), (320, 0, 320, 480)]:
+        x, y, w, h = rect
+        part = util.gpu_render(sr, device, verts, idx, images, ubo, 640, 480, samples, rect=rect)[0]
+        for key in ("tri", "depth", "bgra"):
+            assert np.array_equal(part[key], full[key][y:y + h, x:x + w]), f"{key} differs in rect {rect}"
+        ref = oracle.draw(ubo, verts, idx, images, 640, 480, samples, rect=rect, threads=4)
+        _check_view(part, ref)
+
+
+def test_non_power_of_two_and_mixed_size_textures(sr, oracle, device):
+    rng = np.random.default_rng(2)
+    images = [rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) for (w, h) in [(100, 37), (8, 8), (1, 64), (33, 5)]]
+    verts, idx = sr.scene.uv_sphere(40, 30)
+    verts[:, 6:8] *= 3.0   # exercise REPEAT
+    ubo = sr.scene.default_camera_ubo(400, 300)
+    got = util.gpu_render(sr, device, verts, idx, images, ubo, 400, 300, 1)[0]
+    ref = oracle.draw(ubo, verts, idx, images, 400, 300, 1, threads=4)
+    _check_view(got, ref)
+
+
+@pytest.mark.parametrize("size", [(256, 256), (64, 16), (100, 37), (1, 64), (5, 1), (1, 1)])
+def test_mip_chain_bit_exact(sr, oracle, device, size):
+    w, h = size
+    img = np.random.default_rng(w * 131 + h).integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    tex = sr.create_texture(device, img)
+    chain = oracle.build_mip_chain(img)
+    assert tex.mip_levels == oracle.mip_levels(w, h)
+    for level in range(tex.mip_levels):
+        assert np.array_equal(tex.read_level(level), oracle.chain_level(chain, w, h, level)), f"level {level} differs"
+    tex.destroy()
+
+
+def test_golden_fixtures(sr, device):
+    """The committed oracle outputs (tests/golden/make_golden.py) reproduced by the GPU path."""
+    import make_golden
+    for name in make_golden.SCENES:
+        sc = make_golden.build_scene(name)
+        g = np.load(make_golden.path_of(name))
+        got = util.gpu_render(sr, device, sc["verts"], sc["idx"], sc["images"], sc["ubo"], sc["width"], sc["height"], sc["samples"])[0]
+        _check_view(got, {"tri": g["tri"], "depth": g["depth"], "bgra": g["bgra"]})

@@ -1,0 +1,57 @@
+"""Helpers shared by the parity tests."""
+import numpy as np
+
+GOLDEN_DIR = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def random_soup(n_tris, seed, lo=-1.2, hi=1.2, size=0.25, z_spread=1.0):
+    """Random triangle soup around the origin: independent vertices per triangle, mixed sizes and
+    orientations, with deliberate exact duplicates (coplanar ties) every 7th triangle."""
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(lo, hi, size=(n_tris, 1, 3)).astype(np.float32)
+    centers[..., 2] *= z_spread
+    scale = (size * rng.uniform(0.02, 1.0, size=(n_tris, 1, 1)) ** 2).astype(np.float32)
+    offs = rng.uniform(-1, 1, size=(n_tris, 3, 3)).astype(np.float32) * scale
+    pos = centers + offs
+    dup = np.arange(7, n_tris, 7)
+    pos[dup] = pos[dup - 1]
+    verts = np.zeros((n_tris * 3, 8), np.float32)
+    verts[:, 0:3] = pos.reshape(-1, 3)
+    nrm = rng.normal(size=(n_tris * 3, 3)).astype(np.float32)
+    verts[:, 3:6] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    verts[:, 6:8] = rng.uniform(-2, 3, size=(n_tris * 3, 2)).astype(np.float32)
+    idx = np.arange(n_tris * 3, dtype=np.uint32)
+    return verts, idx
+
+
+def color_match_fraction(a, b, tol=1):
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32)).max(axis=-1)
+    return float((d <= tol).mean()), int(d.max())
+
+
+def gpu_render(sr, device, verts, idx, images, ubos, width, height, samples=1, rect=None, textures=None):
+    """Draw through the C ABI and read everything back.  Returns a list of per-view dicts."""
+    ubos = np.atleast_2d(np.asarray(ubos, np.float32))
+    mesh = sr.create_mesh_from_data(device, verts, idx)
+    tex = textures if textures is not None else [sr.create_texture(device, im) for im in images]
+    tgt = sr.RenderTarget(device, width, height, samples=samples, n_views=ubos.shape[0], rect=rect)
+    try:
+        sr.draw(device, tgt, mesh, ubos, tex)
+        out = [{"tri": tgt.read_triangle_ids(v), "depth": tgt.read_depth(v), "bgra": tgt.read_color(v), "vis": tgt.read_visibility(v)}
+               for v in range(ubos.shape[0])]
+        stats = tgt.stats()
+        for o in out:
+            o["stats"] = stats
+        return out
+    finally:
+        tgt.destroy()
+        mesh.destroy()
+        if textures is None:
+            for t in tex:
+                t.destroy()
+
+
+def assert_visibility_equal(got, ref):
+    assert np.array_equal(got["tri"], ref["tri"]), f"triangle ids differ at {int((got['tri'] != ref['tri']).sum())} samples"
+    assert np.array_equal(got["depth"].view(np.uint32), ref["depth"].view(np.uint32)), \
+        f"depth bits differ at {int((got['depth'].view(np.uint32) != ref['depth'].view(np.uint32)).sum())} samples"

@@ -1,0 +1,645 @@
+// C ABI of the rasteriser (include/softraster.h): handle management, uploads, the draw sequence
+// and read-backs.  Thin by design: everything per-vertex, per-triangle or per-pixel runs in the
+// kernels of sr_kernels.hip; there is no CPU rendering path in this library.
+#include "../../include/softraster.h"
+#include "sr_launch.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string& msg)
+{
+    g_last_error = msg;
+    return status;
+}
+
+#define SR_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(e__ == hipErrorOutOfMemory ? SR_ERR_OUT_OF_MEMORY : SR_ERR_DEVICE,             \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                           \
+    } while (0)
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (ptr) { hipError_t e = hipFree(ptr); ptr = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&ptr, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+};
+
+constexpr int kNumStageEvents = 7;   // start, vertex, setup, scan, fill, raster, fragment
+constexpr int kCountersPerPass = 4;  // total refs, dropped refs, unprojectable triangles, spare
+
+}  // namespace
+
+struct sr_device_t {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    float* d_decode = nullptr;   // 256
+    float* d_thresh = nullptr;   // 255 (+1 pad)
+    // scratch reused by every draw on this device (in-order on `stream`)
+    DeviceBuffer screen, tile_count, tile_offset, survivors, survivor_count, refs, views, counters;
+    // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
+    // wait for each other on the host
+    struct Staging { ViewXform* h = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool in_flight = false; };
+    Staging staging[4];
+    unsigned staging_next = 0;
+    uint64_t ref_capacity = 0;
+    size_t scratch_budget = (size_t)16 << 30;
+    int tile_log2_override = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> events;   // kNumStageEvents per pass of the last profiled draw
+    size_t events_used = 0;
+};
+
+struct sr_mesh_t {
+    void* d_aos = nullptr;
+    float *px = nullptr, *py = nullptr, *pz = nullptr;
+    uint32_t* d_idx = nullptr;
+    uint32_t n_verts = 0, n_tris = 0;
+};
+
+struct sr_texture_t {
+    uint32_t* d_chain = nullptr;
+    int w = 0, h = 0, levels = 0;
+    sr_sampler_desc samp{};
+    uint32_t level_off[kMaxMipLevels] = {};
+    size_t total_texels = 0;
+};
+
+struct sr_target_t {
+    FrameGeom g{};
+    uint32_t n_views = 0;
+    uint64_t* d_vis = nullptr;
+    uint32_t* d_color_own = nullptr;
+    uint32_t* d_color = nullptr;
+    // the last draw, kept so that it can be re-issued if the reference list was too small
+    bool drawn = false, check_pending = false;
+    sr_mesh mesh = nullptr;
+    sr_texture tex[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<ViewXform> views;
+    uint32_t passes = 0;
+    uint32_t* h_counters = nullptr; size_t h_counters_cap = 0;   // pinned, [passes][4], written by the last draw
+    uint64_t capacity_at_draw = 0;
+    uint64_t total_refs = 0, unprojectable = 0, binned = 0;
+};
+
+namespace {
+
+double srgb_decode_d(double x) { return x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4); }
+
+void mat4_mul_mat4_host(const float* A, const float* B, float* R)
+{
+    for (int c = 0; c < 4; ++c) mat4_mul_vec4(A, B[4 * c], B[4 * c + 1], B[4 * c + 2], B[4 * c + 3], R + 4 * c);
+}
+
+TexDesc make_tex_desc(const sr_texture_t* t)
+{
+    TexDesc d{};
+    d.texels = t->d_chain; d.w = t->w; d.h = t->h; d.levels = t->levels;
+    d.min_lod = t->samp.min_lod;
+    d.max_lod = t->samp.max_lod < 0.0f ? (float)t->levels : t->samp.max_lod;
+    d.bias = t->samp.mip_lod_bias;
+    std::memcpy(d.level_off, t->level_off, sizeof d.level_off);
+    return d;
+}
+
+int choose_tile_log2(const sr_device_t* dev, int samples)
+{
+    if (dev->tile_log2_override && raster_config_supported(samples, dev->tile_log2_override)) return dev->tile_log2_override;
+    return samples == 1 ? 6 : 5;
+}
+
+// per-view scratch bytes of a pass
+size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g)
+{
+    return (size_t)m->n_verts * sizeof(ScreenVertex) + (size_t)m->n_tris * sizeof(uint2) + (size_t)g.tiles_x * g.tiles_y * 8 + 64;
+}
+
+uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views)
+{
+    size_t pv = per_view_bytes(m, g);
+    uint64_t by_mem = std::max<uint64_t>(1, dev->scratch_budget / std::max<size_t>(pv, 1));
+    uint64_t by_refs = std::max<uint64_t>(1, (uint64_t)0x7FFFFFFF / std::max<uint32_t>(m->n_tris, 1));
+    uint64_t v = std::min<uint64_t>({(uint64_t)n_views, by_mem, by_refs, (uint64_t)65535});
+    return (uint32_t)std::max<uint64_t>(v, 1);
+}
+
+// issues every kernel of one draw (all passes) on the device's stream
+int issue_draw(sr_device_t* dev, sr_target_t* tg)
+{
+    const sr_mesh_t* m = tg->mesh;
+    const FrameGeom& g = tg->g;
+    const uint32_t n_views = (uint32_t)tg->views.size();
+    const uint32_t vpp = views_per_pass(dev, m, g, n_views);
+    const uint32_t passes = (n_views + vpp - 1) / vpp;
+    const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
+    hipStream_t st = dev->stream;
+
+    if (dev->ref_capacity == 0) dev->ref_capacity = std::max<uint64_t>((uint64_t)m->n_tris * vpp, (uint64_t)1 << 20);
+    dev->ref_capacity = std::min<uint64_t>(dev->ref_capacity, 0xFFFFFFFFull);
+
+    // binning state of a pass lives in one allocation so that one memset clears it:
+    // [tile_count: vpp*n_tiles][survivor_count: vpp]
+    const size_t count_words = (size_t)vpp * n_tiles + vpp;
+    SR_HIP(dev->screen.ensure((size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex)));
+    SR_HIP(dev->tile_count.ensure(count_words * 4));
+    SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
+    SR_HIP(dev->survivors.ensure((size_t)vpp * std::max<uint32_t>(m->n_tris, 1) * sizeof(uint2)));
+    SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
+    SR_HIP(dev->views.ensure((size_t)n_views * sizeof(ViewXform)));
+    SR_HIP(dev->counters.ensure((size_t)passes * kCountersPerPass * 4));
+    sr_device_t::Staging& sg = dev->staging[dev->staging_next++ & 3u];
+    if (!sg.ev) SR_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
+    if (sg.in_flight) { SR_HIP(hipEventSynchronize(sg.ev)); sg.in_flight = false; }
+    if (sg.cap < n_views) {
+        if (sg.h) SR_HIP(hipHostFree(sg.h));
+        sg.h = nullptr; sg.cap = 0;
+        SR_HIP(hipHostMalloc((void**)&sg.h, (size_t)n_views * sizeof(ViewXform), hipHostMallocDefault));
+        sg.cap = n_views;
+    }
+    if (tg->h_counters_cap < passes) {
+        SR_HIP(hipStreamSynchronize(st));
+        if (tg->h_counters) SR_HIP(hipHostFree(tg->h_counters));
+        tg->h_counters = nullptr; tg->h_counters_cap = 0;
+        SR_HIP(hipHostMalloc((void**)&tg->h_counters, (size_t)passes * kCountersPerPass * 4, hipHostMallocDefault));
+        tg->h_counters_cap = passes;
+    }
+    if (dev->profiling) {
+        while (dev->events.size() < (size_t)passes * kNumStageEvents) {
+            hipEvent_t e; SR_HIP(hipEventCreate(&e));
+            dev->events.push_back(e);
+        }
+        dev->events_used = (size_t)passes * kNumStageEvents;
+    } else dev->events_used = 0;
+
+    std::memcpy(sg.h, tg->views.data(), (size_t)n_views * sizeof(ViewXform));
+    SR_HIP(hipMemcpyAsync(dev->views.ptr, sg.h, (size_t)n_views * sizeof(ViewXform), hipMemcpyHostToDevice, st));
+    SR_HIP(hipEventRecord(sg.ev, st));
+    sg.in_flight = true;
+    SR_HIP(hipMemsetAsync(dev->counters.ptr, 0, (size_t)passes * kCountersPerPass * 4, st));
+
+    BinBuffers b{};
+    b.tile_count = (uint32_t*)dev->tile_count.ptr;
+    b.survivor_count = b.tile_count + (size_t)vpp * n_tiles;
+    b.tile_offset = (uint32_t*)dev->tile_offset.ptr;
+    b.refs = (uint32_t*)dev->refs.ptr;
+    b.ref_capacity = (uint32_t)dev->ref_capacity;
+    b.survivors = (uint2*)dev->survivors.ptr;
+
+    const sr_texture_t* albedo = tg->tex[0];
+    const sr_texture_t* metallic = tg->tex[2];
+    const sr_texture_t* roughness = tg->tex[3];
+
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        const uint32_t v0 = pass * vpp, nv = std::min(vpp, n_views - v0);
+        const ViewXform* d_views = (const ViewXform*)dev->views.ptr + v0;
+        b.counters = (uint32_t*)dev->counters.ptr + (size_t)pass * kCountersPerPass;
+        hipEvent_t* ev = dev->profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
+        if (ev) SR_HIP(hipEventRecord(ev[0], st));
+        launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, (ScreenVertex*)dev->screen.ptr, nullptr);
+        if (ev) SR_HIP(hipEventRecord(ev[1], st));
+        SR_HIP(hipMemsetAsync(b.tile_count, 0, count_words * 4, st));
+        launch_setup(st, m->d_idx, m->n_tris, (const ScreenVertex*)dev->screen.ptr, m->n_verts, g, b, nv);
+        if (ev) SR_HIP(hipEventRecord(ev[2], st));
+        launch_scan(st, b, nv * n_tiles, nv);
+        if (ev) SR_HIP(hipEventRecord(ev[3], st));
+        launch_fill(st, g, b, m->n_tris, nv);
+        if (ev) SR_HIP(hipEventRecord(ev[4], st));
+        launch_raster(st, m->d_idx, (const ScreenVertex*)dev->screen.ptr, m->n_verts, g, b, tg->d_vis, v0, nv);
+        if (ev) SR_HIP(hipEventRecord(ev[5], st));
+        FragLaunch f{};
+        f.idx = m->d_idx; f.verts_aos = m->d_aos; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
+        f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
+        f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv;
+        launch_fragment(st, f);
+        if (ev) SR_HIP(hipEventRecord(ev[6], st));
+    }
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(tg->h_counters, dev->counters.ptr, (size_t)passes * kCountersPerPass * 4, hipMemcpyDeviceToHost, st));
+    tg->passes = passes;
+    tg->capacity_at_draw = dev->ref_capacity;
+    tg->check_pending = true;
+    return SR_OK;
+}
+
+// waits for the target's last draw; re-issues it once with a larger reference list if it overflowed
+int finish_target(sr_device_t* dev, sr_target_t* tg)
+{
+    SR_HIP(hipStreamSynchronize(dev->stream));
+    if (!tg->check_pending) return SR_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        uint64_t worst = 0, total = 0, unproj = 0, binned = 0;
+        for (uint32_t p = 0; p < tg->passes; ++p) {
+            const uint32_t* c = tg->h_counters + (size_t)p * kCountersPerPass;
+            worst = std::max<uint64_t>(worst, c[0]); total += c[0]; unproj += c[2]; binned += c[3];
+        }
+        tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned;
+        if (worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
+        if (attempt == 1) break;
+        dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull);
+        int rc = issue_draw(dev, tg);
+        if (rc != SR_OK) return rc;
+        SR_HIP(hipStreamSynchronize(dev->stream));
+    }
+    return fail(SR_ERR_UNSUPPORTED, "tile reference list exceeds 2^32 entries in one pass");
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* sr_status_string(int status)
+{
+    switch (status) {
+    case SR_OK: return "ok";
+    case SR_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case SR_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case SR_ERR_DEVICE: return "HIP call failed";
+    case SR_ERR_INDEX_OUT_OF_RANGE: return "vertex index out of range";
+    case SR_ERR_UNSUPPORTED: return "unsupported configuration";
+    case SR_ERR_NO_DEVICE: return "no gfx950 device";
+    default: return "unknown status";
+    }
+}
+
+const char* sr_last_error_string(void) { return g_last_error.c_str(); }
+
+int sr_device_create(int hip_ordinal, sr_device* out)
+{
+    if (!out) return fail(SR_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return fail(SR_ERR_NO_DEVICE, "no HIP device visible"); }
+    if (hip_ordinal < 0 || hip_ordinal >= count) return fail(SR_ERR_NO_DEVICE, "HIP ordinal out of range");
+    hipDeviceProp_t prop;
+    SR_HIP(hipGetDeviceProperties(&prop, hip_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SR_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    SR_HIP(hipSetDevice(hip_ordinal));
+    sr_device_t* dev = new sr_device_t();
+    dev->ordinal = hip_ordinal;
+    SR_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
+    float dec[256], thr[256];
+    for (int c = 0; c < 256; ++c) dec[c] = (float)srgb_decode_d(c / 255.0);
+    for (int c = 0; c < 255; ++c) thr[c] = (float)srgb_decode_d((c + 0.5) / 255.0);
+    thr[255] = 3.0e38f;
+    SR_HIP(hipMalloc((void**)&dev->d_decode, sizeof dec));
+    SR_HIP(hipMalloc((void**)&dev->d_thresh, sizeof thr));
+    SR_HIP(hipMemcpy(dev->d_decode, dec, sizeof dec, hipMemcpyHostToDevice));
+    SR_HIP(hipMemcpy(dev->d_thresh, thr, sizeof thr, hipMemcpyHostToDevice));
+    if (const char* e = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(e);
+    if (const char* e = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 30;
+    *out = dev;
+    return SR_OK;
+}
+
+int sr_device_destroy(sr_device dev)
+{
+    if (!dev) return SR_OK;
+    (void)hipSetDevice(dev->ordinal);
+    (void)hipStreamSynchronize(dev->stream);
+    for (hipEvent_t e : dev->events) (void)hipEventDestroy(e);
+    dev->screen.release(); dev->tile_count.release(); dev->tile_offset.release(); dev->survivors.release();
+    dev->survivor_count.release(); dev->refs.release(); dev->views.release(); dev->counters.release();
+    for (auto& sg : dev->staging) { if (sg.h) (void)hipHostFree(sg.h); if (sg.ev) (void)hipEventDestroy(sg.ev); }
+    (void)hipFree(dev->d_decode); (void)hipFree(dev->d_thresh);
+    (void)hipStreamDestroy(dev->stream);
+    delete dev;
+    return SR_OK;
+}
+
+int sr_device_synchronize(sr_device dev)
+{
+    if (!dev) return fail(SR_ERR_INVALID_ARGUMENT, "device is NULL");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    SR_HIP(hipStreamSynchronize(dev->stream));
+    return SR_OK;
+}
+
+// ---- mesh ---------------------------------------------------------------------------------------
+int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, sr_mesh* out)
+{
+    if (!dev || !out) return fail(SR_ERR_INVALID_ARGUMENT, "device or out is NULL");
+    *out = nullptr;
+    if ((n_vertices && !vertices) || (n_indices && !indices)) return fail(SR_ERR_INVALID_ARGUMENT, "NULL data with a non-zero count");
+    const uint32_t n_tris = n_indices / 3;   // an incomplete trailing primitive is not drawn
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        if (indices[i] >= n_vertices) return fail(SR_ERR_INDEX_OUT_OF_RANGE, "index " + std::to_string(i) + " = " + std::to_string(indices[i]) + " >= " + std::to_string(n_vertices));
+    SR_HIP(hipSetDevice(dev->ordinal));
+    sr_mesh_t* m = new sr_mesh_t();
+    m->n_verts = n_vertices; m->n_tris = n_tris;
+    const size_t nv = std::max<uint32_t>(n_vertices, 1), ni = std::max<uint32_t>(n_tris * 3, 1);
+    hipError_t e = hipMalloc(&m->d_aos, nv * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->px, nv * 12);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_idx, ni * 4);
+    if (e != hipSuccess) { (void)hipFree(m->d_aos); (void)hipFree(m->px); (void)hipFree(m->d_idx); delete m; SR_HIP(e); }
+    m->py = m->px + nv; m->pz = m->py + nv;
+    if (n_vertices) SR_HIP(hipMemcpyAsync(m->d_aos, vertices, (size_t)n_vertices * 32, hipMemcpyHostToDevice, dev->stream));
+    if (n_tris) SR_HIP(hipMemcpyAsync(m->d_idx, indices, (size_t)n_tris * 12, hipMemcpyHostToDevice, dev->stream));
+    launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipStreamSynchronize(dev->stream));   // uploaded on return, like the reference's blocking staging copy
+    *out = m;
+    return SR_OK;
+}
+
+int sr_mesh_destroy(sr_device dev, sr_mesh mesh)
+{
+    if (!mesh) return SR_OK;
+    if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
+    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx);
+    delete mesh;
+    return SR_OK;
+}
+
+// ---- texture ------------------------------------------------------------------------------------
+void sr_sampler_default(sr_sampler_desc* out)
+{
+    if (!out) return;
+    out->min_lod = 0.0f; out->max_lod = -1.0f; out->mip_lod_bias = 0.0f; out->max_anisotropy = 16.0f;
+}
+
+int sr_texture_create_rgba8_srgb(sr_device dev, const void* rgba8, int width, int height, const sr_sampler_desc* sampler, sr_texture* out)
+{
+    if (!dev || !out || !rgba8) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return fail(SR_ERR_INVALID_ARGUMENT, "texture size out of range");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    sr_texture_t* t = new sr_texture_t();
+    t->w = width; t->h = height;
+    int m = std::max(width, height), levels = 1;
+    while (m > 1) { m >>= 1; ++levels; }   // floor(log2(max(w,h))) + 1, src/texture.cpp:187-189
+    t->levels = levels;
+    size_t off = 0;
+    for (int l = 0; l < levels; ++l) { t->level_off[l] = (uint32_t)off; off += (size_t)std::max(width >> l, 1) * std::max(height >> l, 1); }
+    t->total_texels = off;
+    if (sampler) t->samp = *sampler; else sr_sampler_default(&t->samp);
+    hipError_t e = hipMalloc((void**)&t->d_chain, off * 4);
+    if (e != hipSuccess) { delete t; SR_HIP(e); }
+    SR_HIP(hipMemcpyAsync(t->d_chain, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice, dev->stream));
+    for (int l = 1; l < levels; ++l)
+        launch_mip_blit(dev->stream, t->d_chain + t->level_off[l - 1], std::max(width >> (l - 1), 1), std::max(height >> (l - 1), 1),
+                        t->d_chain + t->level_off[l], std::max(width >> l, 1), std::max(height >> l, 1), dev->d_decode, dev->d_thresh);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipStreamSynchronize(dev->stream));
+    *out = t;
+    return SR_OK;
+}
+
+int sr_texture_destroy(sr_device dev, sr_texture tex)
+{
+    if (!tex) return SR_OK;
+    if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
+    (void)hipFree(tex->d_chain);
+    delete tex;
+    return SR_OK;
+}
+
+int sr_texture_mip_levels(sr_texture tex) { return tex ? tex->levels : 0; }
+
+int sr_texture_read_level(sr_device dev, sr_texture tex, int level, void* host_rgba8, size_t bytes)
+{
+    if (!dev || !tex || !host_rgba8) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (level < 0 || level >= tex->levels) return fail(SR_ERR_INVALID_ARGUMENT, "mip level out of range");
+    const size_t need = (size_t)std::max(tex->w >> level, 1) * std::max(tex->h >> level, 1) * 4;
+    if (bytes != need) return fail(SR_ERR_INVALID_ARGUMENT, "host buffer must hold exactly " + std::to_string(need) + " bytes");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    SR_HIP(hipStreamSynchronize(dev->stream));
+    SR_HIP(hipMemcpy(host_rgba8, tex->d_chain + tex->level_off[level], need, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// ---- target -------------------------------------------------------------------------------------
+int sr_target_create(sr_device dev, int width, int height, int samples, uint32_t n_views, const sr_rect* rect, sr_target* out)
+{
+    if (!dev || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384) return fail(SR_ERR_INVALID_ARGUMENT, "frame size out of range (1..16384)");
+    if (samples != 1 && samples != 4) return fail(SR_ERR_UNSUPPORTED, "samples must be 1 or 4");
+    if (n_views == 0) return fail(SR_ERR_INVALID_ARGUMENT, "n_views must be > 0");
+    sr_rect r = {0, 0, width, height};
+    if (rect) r = *rect;
+    if (r.x < 0 || r.y < 0 || r.width <= 0 || r.height <= 0 || r.x + r.width > width || r.y + r.height > height)
+        return fail(SR_ERR_INVALID_ARGUMENT, "rect must lie inside the frame");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    sr_target_t* t = new sr_target_t();
+    FrameGeom& g = t->g;
+    g.W = width; g.H = height; g.rx = r.x; g.ry = r.y; g.rw = r.width; g.rh = r.height; g.samples = samples;
+    g.tile_log2 = choose_tile_log2(dev, samples);
+    g.tiles_x = (g.rw + (1 << g.tile_log2) - 1) >> g.tile_log2;
+    g.tiles_y = (g.rh + (1 << g.tile_log2) - 1) >> g.tile_log2;
+    if (g.tiles_x > 256 || g.tiles_y > 256) { delete t; return fail(SR_ERR_UNSUPPORTED, "more than 256 tiles along one axis"); }
+    t->n_views = n_views;
+    const size_t px = (size_t)g.rw * g.rh;
+    hipError_t e = hipMalloc((void**)&t->d_vis, px * samples * 8 * n_views);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->d_color_own, px * 4 * n_views);
+    if (e != hipSuccess) { (void)hipFree(t->d_vis); delete t; SR_HIP(e); }
+    t->d_color = t->d_color_own;
+    *out = t;
+    return SR_OK;
+}
+
+int sr_target_destroy(sr_device dev, sr_target target)
+{
+    if (!target) return SR_OK;
+    if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
+    (void)hipFree(target->d_vis); (void)hipFree(target->d_color_own);
+    if (target->h_counters) (void)hipHostFree(target->h_counters);
+    delete target;
+    return SR_OK;
+}
+
+int sr_target_bind_color(sr_device dev, sr_target target, void* device_ptr)
+{
+    if (!dev || !target) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    int rc = finish_target(dev, target);
+    if (rc != SR_OK) return rc;
+    target->d_color = device_ptr ? (uint32_t*)device_ptr : target->d_color_own;
+    return SR_OK;
+}
+
+int sr_target_readback(sr_device dev, sr_target target, int kind, uint32_t view, void* host, size_t bytes)
+{
+    if (!dev || !target || !host) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (view >= target->n_views) return fail(SR_ERR_INVALID_ARGUMENT, "view out of range");
+    if (!target->drawn) return fail(SR_ERR_INVALID_ARGUMENT, "nothing has been drawn into this target");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    int rc = finish_target(dev, target);
+    if (rc != SR_OK) return rc;
+    const FrameGeom& g = target->g;
+    const size_t px = (size_t)g.rw * g.rh, ns = px * g.samples;
+    size_t need = 0;
+    switch (kind) {
+    case SR_READ_COLOR_BGRA8: need = px * 4; break;
+    case SR_READ_DEPTH_F32: case SR_READ_TRI_ID_U32: need = ns * 4; break;
+    case SR_READ_VIS_U64: need = ns * 8; break;
+    default: return fail(SR_ERR_INVALID_ARGUMENT, "unknown read-back kind");
+    }
+    if (bytes != need) return fail(SR_ERR_INVALID_ARGUMENT, "host buffer must hold exactly " + std::to_string(need) + " bytes");
+    if (kind == SR_READ_COLOR_BGRA8) {
+        SR_HIP(hipMemcpy(host, target->d_color + px * view, need, hipMemcpyDeviceToHost));
+    } else if (kind == SR_READ_VIS_U64) {
+        SR_HIP(hipMemcpy(host, target->d_vis + ns * view, need, hipMemcpyDeviceToHost));
+    } else {
+        void* tmp = nullptr;
+        SR_HIP(hipMalloc(&tmp, need));
+        launch_split_vis(dev->stream, target->d_vis + ns * view, ns, kind == SR_READ_DEPTH_F32 ? (float*)tmp : nullptr,
+                         kind == SR_READ_TRI_ID_U32 ? (uint32_t*)tmp : nullptr);
+        hipError_t e = hipStreamSynchronize(dev->stream);
+        if (e == hipSuccess) e = hipMemcpy(host, tmp, need, hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        SR_HIP(e);
+    }
+    return SR_OK;
+}
+
+// ---- draw ---------------------------------------------------------------------------------------
+int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_blocks, uint32_t n_views, size_t ubo_stride, const sr_texture textures[4])
+{
+    if (!dev || !target || !mesh || !ubo_blocks || !textures) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_views == 0 || n_views > target->n_views) return fail(SR_ERR_INVALID_ARGUMENT, "n_views must be in 1..target views");
+    if (ubo_stride < 204 || (ubo_stride & 3)) return fail(SR_ERR_INVALID_ARGUMENT, "ubo_stride must be >= 204 and a multiple of 4");
+    if (!textures[0] || !textures[2] || !textures[3]) return fail(SR_ERR_INVALID_ARGUMENT, "albedo, metallic and roughness textures are required");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    // a finished earlier draw tells how many tile references the scene needs: grow before reuse
+    if (target->check_pending && hipStreamQuery(dev->stream) == hipSuccess) {
+        for (uint32_t p = 0; p < target->passes; ++p)
+            if (target->h_counters[(size_t)p * kCountersPerPass] > dev->ref_capacity) {
+                const uint64_t w = target->h_counters[(size_t)p * kCountersPerPass];
+                dev->ref_capacity = std::min<uint64_t>(w + w / 4 + 1024, 0xFFFFFFFFull);
+            }
+    }
+    (void)hipGetLastError();
+    target->mesh = mesh;
+    for (int k = 0; k < 4; ++k) target->tex[k] = textures[k];
+    target->views.resize(n_views);
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const float* u = (const float*)((const char*)ubo_blocks + (size_t)v * ubo_stride);
+        ViewXform& x = target->views[v];
+        std::memcpy(x.model, u, 64);
+        mat4_mul_mat4_host(u + 32, u + 16, x.pv);   // proj * view
+        std::memcpy(x.cam, u + 48, 12);
+        x.pad = 0.0f;
+    }
+    target->drawn = true;
+    return issue_draw(dev, target);
+}
+
+// ---- instrumentation ----------------------------------------------------------------------------
+int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)
+{
+    if (!dev || !target || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!target->drawn) return fail(SR_ERR_INVALID_ARGUMENT, "nothing has been drawn into this target");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    int rc = finish_target(dev, target);
+    if (rc != SR_OK) return rc;
+    const FrameGeom& g = target->g;
+    const sr_mesh_t* m = target->mesh;
+    const uint32_t n_views = (uint32_t)target->views.size();
+    std::memset(out, 0, sizeof *out);
+    out->vertices = (uint64_t)m->n_verts * n_views;
+    out->triangles = (uint64_t)m->n_tris * n_views;
+    out->tile_refs = target->total_refs;
+    out->triangles_unprojectable = target->unprojectable;
+    out->pixels = (uint64_t)g.rw * g.rh * n_views;
+    uint32_t* flags = nullptr; uint64_t* sums = nullptr;
+    SR_HIP(hipMalloc((void**)&flags, (size_t)std::max<uint32_t>(m->n_tris, 1) * 4));
+    hipError_t e = hipMalloc((void**)&sums, 16);
+    if (e != hipSuccess) { (void)hipFree(flags); SR_HIP(e); }
+    e = hipMemsetAsync(sums, 0, 16, dev->stream);
+    const size_t px = (size_t)g.rw * g.rh;
+    for (uint32_t v = 0; v < n_views && e == hipSuccess; ++v) {
+        e = hipMemsetAsync(flags, 0, (size_t)std::max<uint32_t>(m->n_tris, 1) * 4, dev->stream);
+        launch_stats(dev->stream, target->d_vis + px * g.samples * v, px, g.samples, flags, m->n_tris, sums, sums + 1);
+    }
+    uint64_t h[2] = {0, 0};
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    if (e == hipSuccess) e = hipMemcpy(h, sums, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(flags); (void)hipFree(sums);
+    SR_HIP(e);
+    out->shaded_pixels = h[0];
+    out->visible_triangles = h[1];
+    out->triangles_binned = target->binned;
+    return SR_OK;
+}
+
+int sr_profile_enable(sr_device dev, int enabled)
+{
+    if (!dev) return fail(SR_ERR_INVALID_ARGUMENT, "device is NULL");
+    dev->profiling = enabled != 0;
+    return SR_OK;
+}
+
+int sr_profile_get(sr_device dev, sr_stage_times* out)
+{
+    if (!dev || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(out, 0, sizeof *out);
+    if (!dev->events_used) return fail(SR_ERR_INVALID_ARGUMENT, "no profiled draw: call sr_profile_enable before sr_draw");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    SR_HIP(hipStreamSynchronize(dev->stream));
+    float* f = &out->vertex_ms;
+    for (size_t p = 0; p < dev->events_used / kNumStageEvents; ++p) {
+        hipEvent_t* ev = &dev->events[p * kNumStageEvents];
+        for (int k = 0; k < 6; ++k) {
+            float ms = 0.0f;
+            SR_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            f[k] += ms;
+        }
+        float ms = 0.0f;
+        SR_HIP(hipEventElapsedTime(&ms, ev[0], ev[6]));
+        out->total_ms += ms;
+    }
+    return SR_OK;
+}
+
+int sr_debug_vertex_stage(sr_device dev, sr_mesh mesh, const void* ubo_block, int width, int height, float* clip_out, void* screen_out)
+{
+    if (!dev || !mesh || !ubo_block) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (width <= 0 || height <= 0) return fail(SR_ERR_INVALID_ARGUMENT, "bad frame size");
+    SR_HIP(hipSetDevice(dev->ordinal));
+    const uint32_t n = mesh->n_verts;
+    if (!n) return SR_OK;
+    ViewXform x{};
+    const float* u = (const float*)ubo_block;
+    std::memcpy(x.model, u, 64);
+    mat4_mul_mat4_host(u + 32, u + 16, x.pv);
+    std::memcpy(x.cam, u + 48, 12);
+    void *d_view = nullptr, *d_screen = nullptr, *d_clip = nullptr;
+    hipError_t e = hipMalloc(&d_view, sizeof x);
+    if (e == hipSuccess) e = hipMalloc(&d_screen, (size_t)n * 16);
+    if (e == hipSuccess) e = hipMalloc(&d_clip, (size_t)n * 16);
+    if (e == hipSuccess) e = hipMemcpy(d_view, &x, sizeof x, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_vertex(dev->stream, mesh->px, mesh->py, mesh->pz, n, (const ViewXform*)d_view, 1, width, height, (ScreenVertex*)d_screen, (float*)d_clip);
+        e = hipStreamSynchronize(dev->stream);
+    }
+    if (e == hipSuccess && clip_out) e = hipMemcpy(clip_out, d_clip, (size_t)n * 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && screen_out) e = hipMemcpy(screen_out, d_screen, (size_t)n * 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d_view); (void)hipFree(d_screen); (void)hipFree(d_clip);
+    SR_HIP(e);
+    return SR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+// Shared device-side definitions of the gfx950 rasteriser: records that live in HBM, the fixed-point
+// and floating-point conventions every kernel follows, and the per-triangle set-up.
+//
+// Numerical conventions (every kernel that touches visibility obeys them, which is what makes the
+// depth / triangle-id result independent of tile size, bin order, view batching and screen split):
+//   * mat * vec = last column times its component, then fused multiply-adds down to column 0
+//     (shaders/shader.vert:21-26 of the reference; proj*view is formed first, then applied);
+//   * perspective divide multiplies by 1/w; viewport transform is multiply then add, unfused
+//     (viewport of src/main.cpp:564-571: x_f = x_d*W/2 + W/2, y_f = -y_d*H/2 + H/2, z_f = z_d);
+//   * positions snap to 1/256 pixel, round to nearest even; coverage uses 64-bit integer edge
+//     functions with the top-left rule; sample points are the pixel centre (1 sample) or the Vulkan
+//     standard 4-sample pattern;
+//   * depth at a sample is l0*z0 + l1*z1 + l2*z2, l_i = float(E_i) * (1 / float(2*area)),
+//     accumulated as fma(l2, z2, fma(l1, z1, l0*z0));
+//   * the build uses -ffp-contract=off: only the fmaf() calls written here are fused.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sr {
+
+constexpr int kSubpix = 256;
+constexpr int kHalf = 128;
+constexpr float kGuardPx = 1048576.0f;  // 2^20 pixels
+constexpr uint64_t kVisClear = 0x3F800000FFFFFFFFull;  // depth 1.0, no triangle
+constexpr uint32_t kNoTri = 0xFFFFFFFFu;
+constexpr uint32_t kColorClear = 0xFF000000u;  // B,G,R,A = 0,0,0,255 (clear colour of src/main.cpp:920)
+constexpr int kMaxMipLevels = 16;
+
+struct ViewXform {       // one per view, derived on the host from the reference's uniform block
+    float model[16];     // column-major
+    float pv[16];        // proj * view, column-major
+    float cam[3];
+    float pad;
+};
+
+struct ScreenVertex {    // 16 bytes; rw == 0 marks a vertex that cannot be projected
+    int32_t X, Y;        // window coordinates, 1/256 pixel
+    float z;             // depth after the perspective divide
+    float rw;            // 1 / w_clip
+};
+
+struct TexDesc {
+    const uint32_t* texels;  // RGBA8, all levels back to back
+    int w, h, levels;
+    float min_lod, max_lod, bias;
+    uint32_t level_off[kMaxMipLevels];  // in texels
+};
+
+struct FrameGeom {
+    int W, H;                // frame size (viewport)
+    int rx, ry, rw, rh;      // stored rectangle
+    int tiles_x, tiles_y;    // tiles over the stored rectangle
+    int tile_log2;           // tile edge in pixels = 1 << tile_log2
+    int samples;             // 1 or 4
+};
+
+// ---- vertex shader arithmetic -------------------------------------------------------------------
+__host__ __device__ inline void mat4_mul_vec4(const float* M, float x, float y, float z, float w, float* r)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float acc = M[12 + i] * w;
+        acc = fmaf(M[8 + i], z, acc);
+        acc = fmaf(M[4 + i], y, acc);
+        acc = fmaf(M[i], x, acc);
+        r[i] = acc;
+    }
+}
+
+__device__ inline void mat3_mul_vec3(const float* M, float x, float y, float z, float* r)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = M[8 + i] * z;
+        acc = fmaf(M[4 + i], y, acc);
+        acc = fmaf(M[i], x, acc);
+        r[i] = acc;
+    }
+}
+
+// gl_Position and the window-space record of one vertex
+__device__ inline ScreenVertex project_vertex(const ViewXform& vx, float px, float py, float pz, int W, int H, float* clip)
+{
+    float wp[4];
+    mat4_mul_vec4(vx.model, px, py, pz, 1.0f, wp);
+    mat4_mul_vec4(vx.pv, wp[0], wp[1], wp[2], 1.0f, clip);
+    ScreenVertex sv;
+    sv.X = 0; sv.Y = 0; sv.z = 0.0f; sv.rw = 0.0f;
+    const float w = clip[3];
+    if (!(w > 0.0f)) return sv;
+    const float rw = 1.0f / w;
+    const float xd = clip[0] * rw, yd = clip[1] * rw, zd = clip[2] * rw;
+    const float hw = (float)W * 0.5f, hh = (float)H * 0.5f;
+    const float xf = xd * hw + hw;
+    const float yf = yd * (-hh) + hh;
+    if (!(fabsf(xf) <= kGuardPx) || !(fabsf(yf) <= kGuardPx)) return sv;
+    if (!(rw > 0.0f) || isinf(rw)) return sv;
+    sv.X = (int32_t)rintf(xf * (float)kSubpix);
+    sv.Y = (int32_t)rintf(yf * (float)kSubpix);
+    sv.z = zd;
+    sv.rw = rw;
+    return sv;
+}
+
+// ---- triangle set-up -----------------------------------------------------------------------------
+// a = v0, b = v2, c = v1: a front-facing triangle (counter-clockwise on the displayed image) is
+// traversed clockwise in y-down window coordinates, which makes all edge functions >= 0 inside.
+struct TriSetup {
+    int32_t ax, ay, bx, by, cx, cy;
+    int32_t bias_a, bias_b, bias_c;   // 0 on top/left edges, -1 otherwise (edge opposite a, b, c)
+    float z0, z1, z2;                 // depth of v0, v1, v2
+    float rA;                         // 1 / float(2*area)
+    int64_t A;                        // 2*area > 0
+    int32_t minX, maxX, minY, maxY;
+};
+
+__device__ inline bool is_top_left(int32_t dx, int32_t dy) { return dy < 0 || (dy == 0 && dx > 0); }
+
+// 0: culled (back face / degenerate), 1: ok, 2: dropped because a vertex cannot be projected while
+// another can (the triangle would need clipping against w > 0 or the guard band)
+__device__ inline int setup_triangle(const ScreenVertex& v0, const ScreenVertex& v1, const ScreenVertex& v2, TriSetup& t)
+{
+    const int bad = (v0.rw == 0.0f) + (v1.rw == 0.0f) + (v2.rw == 0.0f);
+    if (bad) return bad < 3 ? 2 : 0;
+    const int64_t area2 = (int64_t)(v1.X - v0.X) * (int64_t)(v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (int64_t)(v1.Y - v0.Y);
+    if (area2 >= 0) return 0;
+    t.A = -area2;
+    t.ax = v0.X; t.ay = v0.Y; t.bx = v2.X; t.by = v2.Y; t.cx = v1.X; t.cy = v1.Y;
+    t.bias_a = is_top_left(t.cx - t.bx, t.cy - t.by) ? 0 : -1;
+    t.bias_b = is_top_left(t.ax - t.cx, t.ay - t.cy) ? 0 : -1;
+    t.bias_c = is_top_left(t.bx - t.ax, t.by - t.ay) ? 0 : -1;
+    t.z0 = v0.z; t.z1 = v1.z; t.z2 = v2.z;
+    t.rA = 1.0f / (float)t.A;
+    t.minX = min(v0.X, min(v1.X, v2.X)); t.maxX = max(v0.X, max(v1.X, v2.X));
+    t.minY = min(v0.Y, min(v1.Y, v2.Y)); t.maxY = max(v0.Y, max(v1.Y, v2.Y));
+    return 1;
+}
+
+// edge functions (weights of v0 = a, v2 = b, v1 = c) at a 1/256-pixel position
+__device__ inline void edge_eval(const TriSetup& t, int64_t px, int64_t py, int64_t& Ea, int64_t& Eb, int64_t& Ec)
+{
+    Ea = (int64_t)(t.cx - t.bx) * (py - t.by) - (int64_t)(t.cy - t.by) * (px - t.bx);
+    Eb = (int64_t)(t.ax - t.cx) * (py - t.cy) - (int64_t)(t.ay - t.cy) * (px - t.cx);
+    Ec = (int64_t)(t.bx - t.ax) * (py - t.ay) - (int64_t)(t.by - t.ay) * (px - t.ax);
+}
+
+// sample offsets inside a pixel, 1/256 pixel units (Vulkan standard sample locations)
+__device__ inline int sample_dx(int S, int s) { return S == 1 ? kHalf : (s == 0 ? 96 : s == 1 ? 224 : s == 2 ? 32 : 160); }
+__device__ inline int sample_dy(int S, int s) { return S == 1 ? kHalf : (s == 0 ? 32 : s == 1 ? 96 : s == 2 ? 160 : 224); }
+
+// pixel columns/rows whose samples can lie inside [lo, hi] (1/256 pixel, inclusive)
+template <int S>
+__device__ inline void pixel_span(int32_t lo, int32_t hi, int& p0, int& p1)
+{
+    if (S == 1) {           // sample at +128: lo <= 256p+128 <= hi
+        p0 = (lo - kHalf + kSubpix - 1) >> 8;
+        p1 = (hi - kHalf) >> 8;
+    } else {                // conservative: any pixel the box touches
+        p0 = lo >> 8;
+        p1 = hi >> 8;
+    }
+}
+
+// depth key of a covered sample, or false if the fragment falls outside the clip volume in z
+__device__ inline bool depth_key(const TriSetup& t, int64_t Ea, int64_t Eb, int64_t Ec, uint32_t tri, uint64_t& key)
+{
+    const float l0 = (float)Ea * t.rA, l2 = (float)Eb * t.rA, l1 = (float)Ec * t.rA;
+    float z = fmaf(l2, t.z2, fmaf(l1, t.z1, l0 * t.z0));
+    z = z + 0.0f;
+    if (!(z >= 0.0f && z <= 1.0f)) return false;
+    key = ((uint64_t)__float_as_uint(z) << 32) | (uint64_t)tri;
+    return true;
+}
+
+// launchers implemented by the stage files --------------------------------------------------------
+struct BinBuffers {
+    uint32_t* tile_count;     // [views][tiles]: triangles per tile, consumed by the fill pass
+    uint32_t* tile_offset;    // [views*tiles + 1]: exclusive scan of tile_count
+    uint32_t* refs;           // [capacity]: triangle ids grouped by (view, tile)
+    uint32_t ref_capacity;
+    uint2* survivors;         // [views][max_tris]: {triangle id, packed tile range}
+    uint32_t* survivor_count; // [views]
+    uint32_t* counters;       // [4]: total refs, dropped refs, unprojectable triangles, spare
+};
+
+}  // namespace sr

@@ -1,0 +1,750 @@
+// HIP kernels of the draw path for gfx950 (wave64): vertex transform, triangle set-up + tile binning,
+// per-tile rasterisation into an LDS visibility tile, deferred fragment shading, mip-chain builder.
+// Host launchers at the bottom are what sr_api.hip calls.
+#include "sr_device.h"
+#include "sr_launch.h"
+
+namespace sr {
+
+// =================================================================================================
+// mesh upload helper: split the reference's 32-byte vertex records into position planes
+// =================================================================================================
+__global__ __launch_bounds__(256) void split_positions_kernel(const float4* __restrict__ aos /* 2 float4 per vertex */, uint32_t n,
+                                                              float* __restrict__ px, float* __restrict__ py, float* __restrict__ pz)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = aos[2 * (size_t)i];
+    px[i] = a.x; py[i] = a.y; pz[i] = a.z;
+}
+
+// =================================================================================================
+// stage 1: vertex shader (shaders/shader.vert:20-27) + perspective divide + viewport + snapping
+// one thread per (vertex, view); coalesced 4-byte plane loads, one 16-byte store
+// =================================================================================================
+__global__ __launch_bounds__(256) void vertex_kernel(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                     uint32_t n, const ViewXform* __restrict__ views, int W, int H,
+                                                     ScreenVertex* __restrict__ out, float4* __restrict__ clip_out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t view = blockIdx.y;
+    if (i >= n) return;
+    const ViewXform& vx = views[view];
+    float clip[4];
+    const ScreenVertex sv = project_vertex(vx, px[i], py[i], pz[i], W, H, clip);
+    reinterpret_cast<int4*>(out)[(size_t)view * n + i] = make_int4(sv.X, sv.Y, __float_as_int(sv.z), __float_as_int(sv.rw));
+    if (clip_out) clip_out[(size_t)view * n + i] = make_float4(clip[0], clip[1], clip[2], clip[3]);
+}
+
+// =================================================================================================
+// stage 2a: triangle set-up, culling, tile counting and compaction of the survivors
+// =================================================================================================
+__device__ inline ScreenVertex load_sv(const ScreenVertex* p)
+{
+    const int4 v = *reinterpret_cast<const int4*>(p);
+    ScreenVertex s; s.X = v.x; s.Y = v.y; s.z = __int_as_float(v.z); s.rw = __int_as_float(v.w);
+    return s;
+}
+
+__device__ inline uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <int S>
+__global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris,
+                                                    const ScreenVertex* __restrict__ sv_all, uint32_t n_verts,
+                                                    FrameGeom g, BinBuffers b)
+{
+    const uint32_t view = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = lane_id();
+    const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
+    uint32_t* count = b.tile_count + (size_t)view * n_tiles;
+
+    bool live = false, unproj = false;
+    int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
+    if (t < n_tris) {
+        const uint32_t i0 = idx[3 * (size_t)t], i1 = idx[3 * (size_t)t + 1], i2 = idx[3 * (size_t)t + 2];
+        const ScreenVertex* sv = sv_all + (size_t)view * n_verts;
+        const ScreenVertex v0 = load_sv(sv + i0), v1 = load_sv(sv + i1), v2 = load_sv(sv + i2);
+        TriSetup ts;
+        const int r = setup_triangle(v0, v1, v2, ts);
+        unproj = r == 2;
+        if (r == 1) {
+            int x0, x1, y0, y1;
+            pixel_span<S>(ts.minX, ts.maxX, x0, x1);
+            pixel_span<S>(ts.minY, ts.maxY, y0, y1);
+            x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+            y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+            if (x0 <= x1 && y0 <= y1) {
+                live = true;
+                tx0 = (x0 - g.rx) >> g.tile_log2; tx1 = (x1 - g.rx) >> g.tile_log2;
+                ty0 = (y0 - g.ry) >> g.tile_log2; ty1 = (y1 - g.ry) >> g.tile_log2;
+            }
+        }
+    }
+    // triangles that would need clipping: one add per wave
+    {
+        const uint64_t m = __ballot(unproj);
+        if (m && lane == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&b.counters[2], (uint32_t)__popcll(m));
+    }
+    // per-tile counts: triangles inside one tile (the common case for small triangles) are
+    // aggregated over the wave, one atomic per distinct tile; larger ones add per tile
+    const bool single = live && tx0 == tx1 && ty0 == ty1;
+    const uint32_t my_tile = (uint32_t)(ty0 * g.tiles_x + tx0);
+    {
+        bool pend = single;
+        uint64_t m = __ballot(pend);
+        while (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            const uint32_t lt = (uint32_t)__shfl((int)my_tile, leader);
+            const uint64_t same = __ballot(pend && my_tile == lt);
+            if (lane == (uint32_t)leader) atomicAdd(&count[lt], (uint32_t)__popcll(same));
+            if (my_tile == lt) pend = false;
+            m &= ~same;
+        }
+    }
+    if (live && !single) {
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&count[ty * g.tiles_x + tx], 1u);
+    }
+    // compaction of the survivors: ballot + prefix count, one atomic per wave
+    {
+        const uint64_t m = __ballot(live);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == (uint32_t)leader) base = atomicAdd(&b.survivor_count[view], (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (live) {
+                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t packed = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+                b.survivors[(size_t)view * n_tris + base + rank] = make_uint2(t, packed);
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// stage 2b: exclusive scan of the per-tile counts (all views of the pass at once), one workgroup
+// =================================================================================================
+__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ offset,
+                                                    uint32_t* __restrict__ counters, const uint32_t* __restrict__ survivor_count, uint32_t n_views)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t beg = min(tid * per, n), end = min(beg + per, n);
+    uint32_t s = 0;
+    for (uint32_t i = beg; i < end; ++i) s += count[i];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {   // Hillis-Steele inclusive scan
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t i = beg; i < end; ++i) { offset[i] = run; run += count[i]; }
+    if (tid == 1023u) { offset[n] = part[1023]; counters[0] = part[1023]; }
+    if (tid == 0u) {
+        uint32_t surv = 0;
+        for (uint32_t v = 0; v < n_views; ++v) surv += survivor_count[v];
+        counters[3] = surv;
+    }
+}
+
+// =================================================================================================
+// stage 2c: scatter the survivors into per-tile reference lists
+// =================================================================================================
+__global__ __launch_bounds__(256) void fill_kernel(FrameGeom g, BinBuffers b, uint32_t n_tris)
+{
+    const uint32_t view = blockIdx.y;
+    const uint32_t lane = lane_id();
+    const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
+    uint32_t* count = b.tile_count + (size_t)view * n_tiles;
+    const uint32_t* offset = b.tile_offset + (size_t)view * n_tiles;
+    const uint32_t n = b.survivor_count[view];
+    const uint2* surv = b.survivors + (size_t)view * n_tris;
+    const uint32_t stride = gridDim.x * 256u;
+    const uint32_t n_round = (n + 63u) & ~63u;   // whole waves take part in the ballots
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_round; i += stride) {
+        const bool have = i < n;
+        uint2 rec = make_uint2(0, 0);
+        if (have) rec = surv[i];
+        const int tx0 = rec.y & 255, ty0 = (rec.y >> 8) & 255, tx1 = (rec.y >> 16) & 255, ty1 = rec.y >> 24;
+        const bool single = have && tx0 == tx1 && ty0 == ty1;
+        const uint32_t my_tile = (uint32_t)(ty0 * g.tiles_x + tx0);
+        bool pend = single;
+        uint64_t m = __ballot(pend);
+        while (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            const uint32_t lt = (uint32_t)__shfl((int)my_tile, leader);
+            const uint64_t same = __ballot(pend && my_tile == lt);
+            uint32_t old = 0;
+            if (lane == (uint32_t)leader) old = atomicSub(&count[lt], (uint32_t)__popcll(same));
+            old = (uint32_t)__shfl((int)old, leader);
+            if (pend && my_tile == lt) {
+                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                const uint32_t pos = offset[lt] + old - 1u - rank;
+                if (pos < b.ref_capacity) b.refs[pos] = rec.x; else atomicAdd(&b.counters[1], 1u);
+                pend = false;
+            }
+            m &= ~same;
+        }
+        if (have && !single) {
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    const uint32_t tile = (uint32_t)(ty * g.tiles_x + tx);
+                    const uint32_t pos = offset[tile] + atomicSub(&count[tile], 1u) - 1u;
+                    if (pos < b.ref_capacity) b.refs[pos] = rec.x; else atomicAdd(&b.counters[1], 1u);
+                }
+        }
+    }
+}
+
+// =================================================================================================
+// stage 3: per-tile rasterisation.  One workgroup per (tile, view): the tile's visibility words live
+// in LDS, every covered sample does a 64-bit LDS atomic min on (depth bits << 32 | triangle id), the
+// finished tile is stored to HBM with plain coalesced stores (clear value included, so there is no
+// separate clear pass).  Small triangles: one lane each.  Large ones: the wave takes them in turn
+// and scans the bounding box in 8x8-pixel blocks.
+// =================================================================================================
+struct LaneTri {
+    TriSetup ts;
+    int x0, x1, y0, y1;
+    uint32_t tri;
+};
+
+template <int S>
+__device__ inline void raster_pixel(const TriSetup& ts, uint32_t tri, int x, int y, unsigned long long* cell /* S words */)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int64_t px = (int64_t)x * kSubpix + sample_dx(S, s), py = (int64_t)y * kSubpix + sample_dy(S, s);
+        int64_t Ea, Eb, Ec;
+        edge_eval(ts, px, py, Ea, Eb, Ec);
+        if (((Ea + ts.bias_a) | (Eb + ts.bias_b) | (Ec + ts.bias_c)) < 0) continue;
+        uint64_t key;
+        if (depth_key(ts, Ea, Eb, Ec, tri, key)) atomicMin(cell + s, (unsigned long long)key);
+    }
+}
+
+template <int TL2, int S, int TPB>
+__global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict__ idx, const ScreenVertex* __restrict__ sv_all, uint32_t n_verts,
+                                                     FrameGeom g, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ refs,
+                                                     uint32_t ref_capacity, unsigned long long* __restrict__ vis, uint32_t view0)
+{
+    constexpr int T = 1 << TL2;
+    constexpr int kSmall = 16;   // bounding boxes up to this many pixels are walked by one lane
+    __shared__ unsigned long long tile[T * T * S];
+    const uint32_t tile_id = blockIdx.x, view = blockIdx.y;
+    const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
+    const int tx = (int)(tile_id % (uint32_t)g.tiles_x), ty = (int)(tile_id / (uint32_t)g.tiles_x);
+    const int px0 = g.rx + tx * T, py0 = g.ry + ty * T;                     // absolute pixel origin of the tile
+    const int px1 = min(px0 + T, g.rx + g.rw) - 1, py1 = min(py0 + T, g.ry + g.rh) - 1;
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+
+    for (int i = tid; i < T * T * S; i += TPB) tile[i] = kVisClear;
+    __syncthreads();
+
+    const uint32_t beg = tile_offset[(size_t)view * n_tiles + tile_id];
+    uint32_t end = tile_offset[(size_t)view * n_tiles + tile_id + 1];
+    end = min(end, ref_capacity);
+    const ScreenVertex* sv = sv_all + (size_t)view * n_verts;
+
+    for (uint32_t base = beg; base < end; base += TPB) {
+        const uint32_t r = base + tid;
+        bool have = r < end;
+        LaneTri L;
+        int npix = 0;
+        if (have) {
+            L.tri = refs[r];
+            const uint32_t i0 = idx[3 * (size_t)L.tri], i1 = idx[3 * (size_t)L.tri + 1], i2 = idx[3 * (size_t)L.tri + 2];
+            const ScreenVertex v0 = load_sv(sv + i0), v1 = load_sv(sv + i1), v2 = load_sv(sv + i2);
+            have = setup_triangle(v0, v1, v2, L.ts) == 1;
+            if (have) {
+                pixel_span<S>(L.ts.minX, L.ts.maxX, L.x0, L.x1);
+                pixel_span<S>(L.ts.minY, L.ts.maxY, L.y0, L.y1);
+                L.x0 = max(L.x0, px0); L.x1 = min(L.x1, px1);
+                L.y0 = max(L.y0, py0); L.y1 = min(L.y1, py1);
+                have = L.x0 <= L.x1 && L.y0 <= L.y1;
+                if (have) npix = (L.x1 - L.x0 + 1) * (L.y1 - L.y0 + 1);
+            }
+        }
+        if (have && npix <= kSmall) {
+            for (int y = L.y0; y <= L.y1; ++y)
+                for (int x = L.x0; x <= L.x1; ++x)
+                    raster_pixel<S>(L.ts, L.tri, x, y, &tile[((y - py0) * T + (x - px0)) * S]);
+        }
+        uint64_t big = __ballot(have && npix > kSmall);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            TriSetup ts;
+            ts.ax = __shfl(L.ts.ax, src); ts.ay = __shfl(L.ts.ay, src);
+            ts.bx = __shfl(L.ts.bx, src); ts.by = __shfl(L.ts.by, src);
+            ts.cx = __shfl(L.ts.cx, src); ts.cy = __shfl(L.ts.cy, src);
+            ts.bias_a = __shfl(L.ts.bias_a, src); ts.bias_b = __shfl(L.ts.bias_b, src); ts.bias_c = __shfl(L.ts.bias_c, src);
+            ts.z0 = __shfl(L.ts.z0, src); ts.z1 = __shfl(L.ts.z1, src); ts.z2 = __shfl(L.ts.z2, src);
+            ts.rA = __shfl(L.ts.rA, src);
+            const int x0 = __shfl(L.x0, src), x1 = __shfl(L.x1, src), y0 = __shfl(L.y0, src), y1 = __shfl(L.y1, src);
+            const uint32_t tri = (uint32_t)__shfl((int)L.tri, src);
+            const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+            for (int by = y0; by <= y1; by += 8)
+                for (int bx = x0; bx <= x1; bx += 8) {
+                    const int x = bx + lx, y = by + ly;
+                    if (x <= x1 && y <= y1) raster_pixel<S>(ts, tri, x, y, &tile[((y - py0) * T + (x - px0)) * S]);
+                }
+        }
+    }
+    __syncthreads();
+
+    const int tw = px1 - px0 + 1, th = py1 - py0 + 1;
+    unsigned long long* out = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
+    for (int i = tid; i < T * T * S; i += TPB) {
+        const int s = i % S, p = i / S, lx = p & (T - 1), ly = p >> TL2;
+        if (lx < tw && ly < th) out[((size_t)(py0 - g.ry + ly) * g.rw + (px0 - g.rx + lx)) * S + s] = tile[i];
+    }
+}
+
+// =================================================================================================
+// stage 4: deferred fragment shading (shaders/shader.frag:102-152) from the visibility buffer
+// =================================================================================================
+struct ShadeTables {
+    const float* decode;   // 256: sRGB code -> linear
+    const float* thresh;   // 255: linear value where the code steps from c to c+1
+};
+
+__device__ inline int srgb_encode8(float x, const float* thresh /* LDS or global, 255 entries */)
+{
+    if (!(x > 0.0f)) return 0;
+    if (x >= thresh[254]) return 255;
+    const float e = x <= 0.0031308f ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
+    int c = (int)(e * 255.0f + 0.5f);
+    c = min(max(c, 0), 254);
+    while (c < 254 && x >= thresh[c]) ++c;      // exact: smallest c with x < thresh[c]
+    while (c > 0 && x < thresh[c - 1]) --c;
+    return c;
+}
+__device__ inline int unorm_encode8(float x)
+{
+    if (!(x > 0.0f)) return 0;
+    if (x > 1.0f) x = 1.0f;
+    return (int)rintf(x * 255.0f);
+}
+
+__device__ inline int wrap_repeat(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+
+// bilinear fetch of NCH leading channels from one level
+template <int NCH>
+__device__ inline void sample_level(const TexDesc& t, int level, float s, float tt, const float* dec, float* o)
+{
+    const int wl = max(t.w >> level, 1), hl = max(t.h >> level, 1);
+    const uint32_t* base = t.texels + t.level_off[level];
+    const float u = s * (float)wl - 0.5f, v = tt * (float)hl - 0.5f;
+    float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const float lim = 1073741824.0f;
+    if (!(fu > -lim)) fu = -lim; if (fu > lim) fu = lim;
+    if (!(fv > -lim)) fv = -lim; if (fv > lim) fv = lim;
+    int i0, j0, i1, j1;
+    if (((wl & (wl - 1)) | (hl & (hl - 1))) == 0) {   // power-of-two level: wrap with a mask
+        i0 = (int)fu & (wl - 1); j0 = (int)fv & (hl - 1);
+        i1 = (i0 + 1) & (wl - 1); j1 = (j0 + 1) & (hl - 1);
+    } else {
+        i0 = wrap_repeat((int)fu, wl); j0 = wrap_repeat((int)fv, hl);
+        i1 = wrap_repeat(i0 + 1, wl); j1 = wrap_repeat(j0 + 1, hl);
+    }
+    const uint32_t c00 = base[(size_t)j0 * wl + i0], c10 = base[(size_t)j0 * wl + i1];
+    const uint32_t c01 = base[(size_t)j1 * wl + i0], c11 = base[(size_t)j1 * wl + i1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int sh = 8 * c;
+        const float t00 = dec[(c00 >> sh) & 255u], t10 = dec[(c10 >> sh) & 255u];
+        const float t01 = dec[(c01 >> sh) & 255u], t11 = dec[(c11 >> sh) & 255u];
+        o[c] = ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;
+    }
+}
+
+// texture() with the 2x2-quad differences supplied; isotropic LOD, trilinear, REPEAT
+template <int NCH>
+__device__ inline void sample_texture(const TexDesc& t, float s, float tt, float dsdx, float dtdx, float dsdy, float dtdy,
+                                      const float* dec, float* o)
+{
+    const float mux = dsdx * (float)t.w, mvx = dtdx * (float)t.h;
+    const float muy = dsdy * (float)t.w, mvy = dtdy * (float)t.h;
+    const float rx2 = mux * mux + mvx * mvx, ry2 = muy * muy + mvy * mvy;
+    const float r2 = rx2 > ry2 ? rx2 : ry2;
+    float lambda = 0.5f * __builtin_amdgcn_logf(r2) + t.bias;
+    if (!(lambda > t.min_lod)) lambda = t.min_lod;
+    if (lambda > t.max_lod) lambda = t.max_lod;
+    const float q = (float)(t.levels - 1);
+    float d = lambda; if (d < 0.0f) d = 0.0f; if (d > q) d = q;
+    const float dhi = floorf(d), delta = d - dhi;
+    const int lhi = (int)dhi, llo = min(lhi + 1, t.levels - 1);
+    float chi[NCH];
+    sample_level<NCH>(t, lhi, s, tt, dec, chi);
+    if (delta == 0.0f) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) o[c] = chi[c];
+        return;
+    }
+    float clo[NCH];
+    sample_level<NCH>(t, llo, s, tt, dec, clo);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) o[c] = (1.0f - delta) * chi[c] + delta * clo[c];
+}
+
+__device__ inline float max0(float x) { return x > 0.0f ? x : 0.0f; }
+__device__ inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ inline void normalize3(const float* a, float* o)
+{
+    const float inv = 1.0f / sqrtf(dot3(a, a));
+    o[0] = a[0] * inv; o[1] = a[1] * inv; o[2] = a[2] * inv;
+}
+__device__ inline float fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }   // pow() of the shader; x >= 0
+
+__device__ inline float geometry_schlick_ggx(float NdotV, float roughness)
+{
+    const float r = roughness + 1.0f, k = (r * r) / 8.0f;
+    return NdotV / (NdotV * (1.0f - k) + k);
+}
+
+// main() of shaders/shader.frag with the three texture() results passed in
+__device__ inline void fragment_main(const float* wp, const float* N, const float* cam, const float* albedo_tex,
+                                     float metallic, float roughness, float* out)
+{
+    const float kPI = 3.14159265359f;
+    const float albedo[3] = { fast_pow(albedo_tex[0], 2.2f), fast_pow(albedo_tex[1], 2.2f), fast_pow(albedo_tex[2], 2.2f) };
+    const float ao = 0.01f;
+    float V[3], t[3];
+    t[0] = cam[0] - wp[0]; t[1] = cam[1] - wp[1]; t[2] = cam[2] - wp[2];
+    normalize3(t, V);
+    float F0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) F0[c] = 0.04f * (1.0f - metallic) + albedo[c] * metallic;
+    float Lo[3] = { 0.0f, 0.0f, 0.0f };
+    const float power[3] = { 23.47f, 21.31f, 20.79f };
+    const float NdotV = max0(dot3(N, V));
+    const float a = roughness * roughness, a2 = a * a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lp[3] = { (i & 1) ? 10.0f : -10.0f, (i & 2) ? -10.0f : 10.0f, 10.0f };
+        float D[3] = { lp[0] - wp[0], lp[1] - wp[1], lp[2] - wp[2] };
+        float L[3], Hv[3];
+        normalize3(D, L);
+        t[0] = V[0] + L[0]; t[1] = V[1] + L[1]; t[2] = V[2] + L[2];
+        normalize3(t, Hv);
+        const float attenuation = 1.0f / dot3(D, D);
+        const float NdotH = max0(dot3(N, Hv)), NdotH2 = NdotH * NdotH;
+        float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
+        denom = kPI * denom * denom;
+        const float NDF = a2 / denom;
+        const float NdotL = max0(dot3(N, L));
+        const float G = geometry_schlick_ggx(NdotL, roughness) * geometry_schlick_ggx(NdotV, roughness);
+        const float fc = fast_pow(1.0f - max0(dot3(Hv, V)), 5.0f);
+        const float denominator = 4.0f * NdotV * NdotL + 0.001f;
+        const float dn = denominator > 0.001f ? denominator : 0.001f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float F = F0[c] + (1.0f - F0[c]) * fc;
+            const float specular = (NDF * G * F) / dn;
+            const float kD = (1.0f - F) * (1.0f - metallic);
+            const float radiance = power[c] * attenuation;
+            Lo[c] += (kD * albedo[c] / kPI + specular) * radiance * NdotL;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float ambient = 0.03f * albedo[c] * ao;
+        float color = ambient + Lo[c];
+        color = color / (color + 1.0f);
+        out[c] = fast_pow(color, 1.0f / 2.2f);
+    }
+}
+
+__device__ inline void persp_weights(const TriSetup& t, float rw0, float rw1, float rw2, int64_t px, int64_t py, float& p0, float& p1, float& p2)
+{
+    int64_t Ea, Eb, Ec;
+    edge_eval(t, px, py, Ea, Eb, Ec);
+    const float l0 = (float)Ea * t.rA, l2 = (float)Eb * t.rA, l1 = (float)Ec * t.rA;
+    const float q0 = l0 * rw0, q1 = l1 * rw1, q2 = l2 * rw2;
+    const float rden = 1.0f / ((q0 + q1) + q2);
+    p0 = q0 * rden; p1 = q1 * rden; p2 = q2 * rden;
+}
+__device__ inline float interp(float p0, float p1, float p2, float a0, float a1, float a2) { return fmaf(p2, a2, fmaf(p1, a1, p0 * a0)); }
+
+struct FragParams {
+    const uint32_t* idx;
+    const float4* verts;       // 2 float4 per vertex: (pos.xyz, n.x) (n.yz, uv)
+    const ViewXform* views;    // views of this pass
+    const unsigned long long* vis;
+    uint32_t* color;
+    FrameGeom g;
+    TexDesc albedo, metallic, roughness;
+    ShadeTables tab;
+    uint32_t view0;            // first view of this pass inside the target
+};
+
+// shades triangle `tri` at pixel (x,y): packed B,G,R,A
+__device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, uint32_t tri, int x, int y, const float* dec, const float* thr)
+{
+    const uint32_t i0 = p.idx[3 * (size_t)tri], i1 = p.idx[3 * (size_t)tri + 1], i2 = p.idx[3 * (size_t)tri + 2];
+    const float4 a0 = p.verts[2 * (size_t)i0], b0 = p.verts[2 * (size_t)i0 + 1];
+    const float4 a1 = p.verts[2 * (size_t)i1], b1 = p.verts[2 * (size_t)i1 + 1];
+    const float4 a2 = p.verts[2 * (size_t)i2], b2 = p.verts[2 * (size_t)i2 + 1];
+    float clip[4];
+    // recomputing the window-space vertices gives bit-identical values to the vertex stage
+    const ScreenVertex v0 = project_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H, clip);
+    const ScreenVertex v1 = project_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H, clip);
+    const ScreenVertex v2 = project_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H, clip);
+    TriSetup ts;
+    setup_triangle(v0, v1, v2, ts);
+    float p0, p1, p2;
+    persp_weights(ts, v0.rw, v1.rw, v2.rw, (int64_t)x * kSubpix + kHalf, (int64_t)y * kSubpix + kHalf, p0, p1, p2);
+    float w0[4], w1[4], w2[4], n0[3], n1[3], n2[3];
+    mat4_mul_vec4(vx.model, a0.x, a0.y, a0.z, 1.0f, w0);
+    mat4_mul_vec4(vx.model, a1.x, a1.y, a1.z, 1.0f, w1);
+    mat4_mul_vec4(vx.model, a2.x, a2.y, a2.z, 1.0f, w2);
+    mat3_mul_vec3(vx.model, a0.w, b0.x, b0.y, n0);
+    mat3_mul_vec3(vx.model, a1.w, b1.x, b1.y, n1);
+    mat3_mul_vec3(vx.model, a2.w, b2.x, b2.y, n2);
+    float wp[3], N[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { wp[k] = interp(p0, p1, p2, w0[k], w1[k], w2[k]); N[k] = interp(p0, p1, p2, n0[k], n1[k], n2[k]); }
+    const float u = interp(p0, p1, p2, b0.z, b1.z, b2.z), v = interp(p0, p1, p2, b0.w, b1.w, b2.w);
+    // coarse derivatives over the pixel's 2x2 quad, evaluated for this triangle at the quad's
+    // top-left, top-right and bottom-left pixel centres (what helper invocations would compute)
+    const int qx = x & ~1, qy = y & ~1;
+    float uq[3], vq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float r0, r1, r2;
+        persp_weights(ts, v0.rw, v1.rw, v2.rw, (int64_t)(qx + (k == 1)) * kSubpix + kHalf, (int64_t)(qy + (k == 2)) * kSubpix + kHalf, r0, r1, r2);
+        uq[k] = interp(r0, r1, r2, b0.z, b1.z, b2.z);
+        vq[k] = interp(r0, r1, r2, b0.w, b1.w, b2.w);
+    }
+    const float dudx = uq[1] - uq[0], dvdx = vq[1] - vq[0], dudy = uq[2] - uq[0], dvdy = vq[2] - vq[0];
+    float alb[3], met[1], rgh[1], rgb[3];
+    sample_texture<3>(p.albedo, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
+    sample_texture<1>(p.metallic, u, v, dudx, dvdx, dudy, dvdy, dec, met);
+    sample_texture<1>(p.roughness, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+    fragment_main(wp, N, vx.cam, alb, met[0], rgh[0], rgb);
+    const uint32_t R = (uint32_t)srgb_encode8(rgb[0] > 1.0f ? 1.0f : rgb[0], thr);
+    const uint32_t G = (uint32_t)srgb_encode8(rgb[1] > 1.0f ? 1.0f : rgb[1], thr);
+    const uint32_t B = (uint32_t)srgb_encode8(rgb[2] > 1.0f ? 1.0f : rgb[2], thr);
+    return B | (G << 8) | (R << 16) | (255u << 24);
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
+{
+    __shared__ float s_dec[256];
+    __shared__ float s_thr[256];
+    const uint32_t tid = threadIdx.y * 32u + threadIdx.x;
+    s_dec[tid] = p.tab.decode[tid];
+    s_thr[tid] = tid < 255u ? p.tab.thresh[tid] : 3.0e38f;
+    __syncthreads();
+    const int lx = (int)(blockIdx.x * 32u + threadIdx.x), ly = (int)(blockIdx.y * 8u + threadIdx.y);
+    const uint32_t view = blockIdx.z;
+    if (lx >= p.g.rw || ly >= p.g.rh) return;
+    const size_t pix = ((size_t)(p.view0 + view) * p.g.rh + ly) * p.g.rw + lx;
+    const unsigned long long* v = p.vis + pix * S;
+    const int x = p.g.rx + lx, y = p.g.ry + ly;
+    const ViewXform& vx = p.views[view];
+    uint32_t ids[S], col[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) ids[s] = (uint32_t)v[s];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (ids[s] == kNoTri) { col[s] = kColorClear; continue; }
+        int prev = -1;
+#pragma unroll
+        for (int k = 0; k < s; ++k) if (prev < 0 && ids[k] == ids[s]) prev = k;
+        if (prev >= 0) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < s; ++k) if (k == prev) c = col[k];
+            col[s] = c;
+        } else {
+            col[s] = shade_pixel(p, vx, ids[s], x, y, s_dec, s_thr);
+        }
+    }
+    uint32_t outc;
+    if (S == 1) outc = col[0];
+    else {
+        outc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const uint32_t b = (col[s] >> (8 * k)) & 255u;
+                acc += k == 3 ? (float)b / 255.0f : s_dec[b];
+            }
+            acc = acc / (float)S;
+            const uint32_t ch = k == 3 ? (uint32_t)unorm_encode8(acc) : (uint32_t)srgb_encode8(acc, s_thr);
+            outc |= ch << (8 * k);
+        }
+    }
+    p.color[pix] = outc;
+}
+
+// =================================================================================================
+// mip-chain builder: one linear blit per level (src/texture.cpp:119-164), sRGB-correct
+// =================================================================================================
+__global__ __launch_bounds__(256) void mip_blit_kernel(const uint32_t* __restrict__ src, int sw, int sh, uint32_t* __restrict__ dst, int dw, int dh,
+                                                       ShadeTables tab)
+{
+    const int i = (int)(blockIdx.x * 32u + (threadIdx.x & 31u)), j = (int)(blockIdx.y * 8u + (threadIdx.x >> 5));
+    if (i >= dw || j >= dh) return;
+    const float sx = (float)sw / (float)dw, sy = (float)sh / (float)dh;
+    const float u = ((float)i + 0.5f) * sx - 0.5f, v = ((float)j + 0.5f) * sy - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const int i0 = min(max((int)fu, 0), sw - 1), i1 = min(max((int)fu + 1, 0), sw - 1);
+    const int j0 = min(max((int)fv, 0), sh - 1), j1 = min(max((int)fv + 1, 0), sh - 1);
+    const uint32_t c00 = src[(size_t)j0 * sw + i0], c10 = src[(size_t)j0 * sw + i1];
+    const uint32_t c01 = src[(size_t)j1 * sw + i0], c11 = src[(size_t)j1 * sw + i1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    uint32_t outc = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int sh8 = 8 * c;
+        const uint32_t b00 = (c00 >> sh8) & 255u, b10 = (c10 >> sh8) & 255u, b01 = (c01 >> sh8) & 255u, b11 = (c11 >> sh8) & 255u;
+        float t00, t10, t01, t11;
+        if (c < 3) { t00 = tab.decode[b00]; t10 = tab.decode[b10]; t01 = tab.decode[b01]; t11 = tab.decode[b11]; }
+        else { t00 = (float)b00 / 255.0f; t10 = (float)b10 / 255.0f; t01 = (float)b01 / 255.0f; t11 = (float)b11 / 255.0f; }
+        const float r = ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;
+        const uint32_t e = c < 3 ? (uint32_t)srgb_encode8(r, tab.thresh) : (uint32_t)unorm_encode8(r);
+        outc |= e << sh8;
+    }
+    dst[(size_t)j * dw + i] = outc;
+}
+
+// =================================================================================================
+// read-back helpers and work counters (not on the timed path)
+// =================================================================================================
+__global__ __launch_bounds__(256) void split_vis_kernel(const unsigned long long* __restrict__ vis, size_t n, float* __restrict__ depth, uint32_t* __restrict__ tri)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long v = vis[i];
+    if (depth) depth[i] = __uint_as_float((uint32_t)(v >> 32));
+    if (tri) tri[i] = (uint32_t)v;
+}
+
+// marks the triangles that own a sample and counts pixels with any covered sample
+__global__ __launch_bounds__(256) void stats_kernel(const unsigned long long* __restrict__ vis, size_t n_pixels, int S, uint32_t* __restrict__ tri_flag,
+                                                    unsigned long long* __restrict__ shaded_pixels)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    bool any = false;
+    if (i < n_pixels)
+        for (int s = 0; s < S; ++s) {
+            const uint32_t id = (uint32_t)vis[i * S + s];
+            if (id != kNoTri) { any = true; tri_flag[id] = 1u; }
+        }
+    const uint64_t m = __ballot(any);
+    if (m && lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(shaded_pixels, (unsigned long long)__popcll(m));
+}
+__global__ __launch_bounds__(256) void count_flags_kernel(const uint32_t* __restrict__ flag, uint32_t n, unsigned long long* __restrict__ total)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool f = i < n && flag[i] != 0u;
+    const uint64_t m = __ballot(f);
+    if (m && lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(total, (unsigned long long)__popcll(m));
+}
+
+// =================================================================================================
+// host launchers
+// =================================================================================================
+static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz)
+{
+    if (!n) return;
+    split_positions_kernel<<<div_up(n, 256), 256, 0, st>>>((const float4*)aos, n, px, py, pz);
+}
+
+void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
+                   int W, int H, ScreenVertex* out, float* clip_out)
+{
+    if (!n || !n_views) return;
+    vertex_kernel<<<dim3(div_up(n, 256), n_views), 256, 0, st>>>(px, py, pz, n, views, W, H, out, (float4*)clip_out);
+}
+
+void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g,
+                  const BinBuffers& b, uint32_t n_views)
+{
+    if (!n_tris || !n_views) return;
+    const dim3 grid(div_up(n_tris, 256), n_views);
+    if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sv, n_verts, g, b);
+    else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sv, n_verts, g, b);
+}
+
+void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views)
+{
+    scan_kernel<<<1, 1024, 0, st>>>(b.tile_count, n_entries, b.tile_offset, b.counters, b.survivor_count, n_views);
+}
+
+void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views)
+{
+    if (!n_tris || !n_views) return;
+    const uint32_t blocks = min(div_up(n_tris, 256), 2048u);
+    fill_kernel<<<dim3(blocks, n_views), 256, 0, st>>>(g, b, n_tris);
+}
+
+void launch_raster(hipStream_t st, const uint32_t* idx, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g, const BinBuffers& b,
+                   uint64_t* vis, uint32_t view0, uint32_t n_views)
+{
+    if (!n_views) return;
+    const dim3 grid((uint32_t)(g.tiles_x * g.tiles_y), n_views);
+    unsigned long long* v = (unsigned long long*)vis;
+    if (g.samples == 1 && g.tile_log2 == 6)
+        raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    else if (g.samples == 1 && g.tile_log2 == 5)
+        raster_kernel<5, 1, 256><<<grid, 256, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    else if (g.samples == 4 && g.tile_log2 == 5)
+        raster_kernel<5, 4, 1024><<<grid, 1024, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    else if (g.samples == 4 && g.tile_log2 == 4)
+        raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+}
+
+bool raster_config_supported(int samples, int tile_log2)
+{
+    return (samples == 1 && (tile_log2 == 5 || tile_log2 == 6)) || (samples == 4 && (tile_log2 == 4 || tile_log2 == 5));
+}
+
+void launch_fragment(hipStream_t st, const FragLaunch& f)
+{
+    if (!f.n_views) return;
+    FragParams p;
+    p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
+    p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness;
+    p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0;
+    const dim3 grid(div_up((uint32_t)f.g.rw, 32), div_up((uint32_t)f.g.rh, 8), f.n_views), block(32, 8);
+    if (f.g.samples == 1) fragment_kernel<1><<<grid, block, 0, st>>>(p);
+    else fragment_kernel<4><<<grid, block, 0, st>>>(p);
+}
+
+void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh)
+{
+    ShadeTables tab; tab.decode = decode; tab.thresh = thresh;
+    mip_blit_kernel<<<dim3(div_up((uint32_t)dw, 32), div_up((uint32_t)dh, 8)), 256, 0, st>>>(src, sw, sh, dst, dw, dh, tab);
+}
+
+void launch_split_vis(hipStream_t st, const uint64_t* vis, size_t n, float* depth, uint32_t* tri)
+{
+    if (!n) return;
+    split_vis_kernel<<<div_up(n, 256), 256, 0, st>>>((const unsigned long long*)vis, n, depth, tri);
+}
+
+void launch_stats(hipStream_t st, const uint64_t* vis, size_t n_pixels, int S, uint32_t* tri_flag, uint32_t n_tris, uint64_t* shaded, uint64_t* visible)
+{
+    if (n_pixels) stats_kernel<<<div_up(n_pixels, 256), 256, 0, st>>>((const unsigned long long*)vis, n_pixels, S, tri_flag, (unsigned long long*)shaded);
+    if (n_tris) count_flags_kernel<<<div_up(n_tris, 256), 256, 0, st>>>(tri_flag, n_tris, (unsigned long long*)visible);
+}
+
+}  // namespace sr

@@ -1,0 +1,36 @@
+// Host-callable launchers of the kernels in sr_kernels.hip.
+#pragma once
+
+#include "sr_device.h"
+
+namespace sr {
+
+struct FragLaunch {
+    const uint32_t* idx;
+    const void* verts_aos;     // the reference's 32-byte vertex records
+    const ViewXform* views;
+    const uint64_t* vis;
+    uint32_t* color;
+    FrameGeom g;
+    TexDesc albedo, metallic, roughness;
+    const float* decode;
+    const float* thresh;
+    uint32_t view0, n_views;
+};
+
+void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz);
+void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
+                   int W, int H, ScreenVertex* out, float* clip_out);
+void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g,
+                  const BinBuffers& b, uint32_t n_views);
+void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views);
+void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views);
+void launch_raster(hipStream_t st, const uint32_t* idx, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g, const BinBuffers& b,
+                   uint64_t* vis, uint32_t view0, uint32_t n_views);
+bool raster_config_supported(int samples, int tile_log2);
+void launch_fragment(hipStream_t st, const FragLaunch& f);
+void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh);
+void launch_split_vis(hipStream_t st, const uint64_t* vis, size_t n, float* depth, uint32_t* tri);
+void launch_stats(hipStream_t st, const uint64_t* vis, size_t n_pixels, int S, uint32_t* tri_flag, uint32_t n_tris, uint64_t* shaded, uint64_t* visible);
+
+}  // namespace sr
