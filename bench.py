@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the draw path: BASELINE config 3 -- one 3840x2160 frame of a 10 M-triangle UV sphere
+with a 4096^2 mip-mapped albedo map (2048^2 metallic / roughness), default reference camera.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one sr_draw (clear, vertex, set-up + binning, raster, fragment) of one view per GPU with
+mesh and textures already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank
+per GPU) every rank draws its own camera of the same orbit: the path shards by view with no
+collective on the data path (weak scaling).  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vulkan-renderer_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+WORKLOADS = {
+    # name: (width, height, sphere X, sphere Y, albedo size, other maps size)
+    "c3_4k_10Mtri": (3840, 2160, 2500, 2000, 4096, 2048),
+    "small_1080p_124ktri": (1920, 1080, 250, 248, 1024, 512),   # for quick checks only
+}
+
+
+def stage_bytes(V, T, R, F, P, Pv, S, survivors):
+    """Algorithmic (compulsory) HBM bytes per stage for one frame: every array counted once per
+    stage that must touch it.  X (unique texels over the three maps) is modelled as Pv*3*1.33."""
+    X = Pv * 3 * 1.33
+    return {
+        "vertex": V * 12 + V * 16,
+        "setup": T * 12 + V * 16 + survivors * 8,
+        "scan": 0,
+        "fill": survivors * 8 + R * 4,
+        "raster": R * 4 + R * 12 + V * 16 + P * S * 8,
+        "fragment": P * S * 8 + F * (12 + 3 * 32) + X * 4 + P * 4,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3_4k_10Mtri", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import softraster as sr
+    W, H, SX, SY, alb_size, map_size = WORKLOADS[args.workload]
+    verts, idx = sr.scene.uv_sphere(SX, SY)
+    images = [sr.scene.albedo_pattern(alb_size), None, sr.scene.gray_map(map_size, map_size, 0, 254), sr.scene.gray_map(map_size, map_size, 72, 255)]
+    # rank r draws view r of a `world`-camera orbit; view 0 is the reference's default camera
+    ubo = sr.scene.default_camera_ubo(W, H, eye=sr.scene.orbit_eye(rank, max(world, 1)) if world > 1 else (2.0, 2.0, 2.0))
+
+    dev = sr.Device(local_rank)
+    mesh = sr.create_mesh_from_data(dev, verts, idx)
+    tex = [sr.create_texture(dev, im) if im is not None else None for im in images]
+    tgt = sr.RenderTarget(dev, W, H, samples=1, n_views=1)
+
+    def barrier():
+        dev.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(max(args.warmup, 1)):   # the first draw also sizes the tile reference list
+        sr.draw(dev, tgt, mesh, ubo, tex)
+    stats = tgt.stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sr.draw(dev, tgt, mesh, ubo, tex)
+    dev.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        torch.cuda.synchronize()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        pv = torch.tensor([float(stats["shaded_pixels"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(pv, op=dist.ReduceOp.SUM)
+        shaded_total = float(pv.item())
+    else:
+        shaded_total = float(stats["shaded_pixels"])
+
+    # per-kernel durations from HIP events on the library's own stream, same K steps
+    dev.profile(True)
+    acc = {}
+    for _ in range(args.steps):
+        sr.draw(dev, tgt, mesh, ubo, tex)
+        for k, v in dev.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v
+    dev.profile(False)
+    stage_ms = {k: v / args.steps for k, v in acc.items()}
+
+    if rank == 0:
+        T = stats["triangles"]; V = stats["vertices"]; R = stats["tile_refs"]; F = stats["visible_triangles"]
+        P = stats["pixels"]; Pv = stats["shaded_pixels"]; surv = stats["triangles_binned"]
+        ms_per_step = elapsed / args.steps * 1e3
+        frames_per_s = world * args.steps / elapsed
+        mtris = T * frames_per_s / 1e6
+        by = stage_bytes(V, T, R, F, P, Pv, 1, surv)
+        kernels = {k: stage_ms[k + "_ms"] for k in ("vertex", "setup", "scan", "fill", "raster", "fragment")}
+        dom = max(kernels, key=kernels.get)
+        achieved = by[dom] / (kernels[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes, if collected
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        frame_bytes = sum(by.values())
+        out = {
+            "metric": "Mtris/s, 3840x2160 frame of a 10M-triangle mesh with 4096^2 mip-mapped texture" if args.workload == "c3_4k_10Mtri" else "Mtris/s",
+            "value": round(mtris, 2), "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "width": W, "height": H, "triangles": T, "vertices": V, "samples": 1,
+                       "views_per_gpu": 1, "sharding": "by view (no collective)" if world > 1 else "single GPU"},
+            "frames_per_s": round(frames_per_s, 2),
+            "gpixels_shaded_per_s": round(shaded_total * args.steps / elapsed / 1e9, 4),
+            "counters": {"V": V, "T": T, "R": R, "F": F, "P": P, "Pv": Pv, "S": 1, "survivors": surv},
+            "kernel_ms": {k: round(v, 4) for k, v in kernels.items()},
+            "frame_algorithmic_bytes": int(frame_bytes),
+            "frame_hbm_fraction": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": int(by[dom])},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            chains = [(oracle.build_mip_chain(im), im.shape[1], im.shape[0]) if im is not None else (np.zeros((1, 4), np.uint8), 1, 1) for im in images]
+            tc = time.perf_counter()
+            oracle.draw(ubo, verts, idx, chains, W, H, 1, threads=threads)
+            cpu_s = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": round(T / cpu_s / 1e6, 3), "unit": "Mtris/s", "cores": threads, "kind": "port",
+                                   "sample": f"one full {W}x{H} frame of the same scene (mip chains prebuilt), {cpu_s:.2f} s"}
+        print(json.dumps(out), flush=True)
+
+    barrier()
+    for t in tex:
+        if t is not None:
+            t.destroy()
+    tgt.destroy(); mesh.destroy(); dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,7 +132,7 @@ int choose_tile_log2(const sr_device_t* dev, int samples)
 // per-view scratch bytes of a pass
 size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g)
 {
-    return (size_t)m->n_verts * sizeof(ScreenVertex) + (size_t)m->n_tris * sizeof(uint2) + (size_t)g.tiles_x * g.tiles_y * 8 + 64;
+    return (size_t)m->n_verts * sizeof(ScreenVertex) + ((size_t)m->n_tris + 256) * sizeof(uint2) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 8 + 64;
 }
 
 uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views)
@@ -158,13 +158,14 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     if (dev->ref_capacity == 0) dev->ref_capacity = std::max<uint64_t>((uint64_t)m->n_tris * vpp, (uint64_t)1 << 20);
     dev->ref_capacity = std::min<uint64_t>(dev->ref_capacity, 0xFFFFFFFFull);
 
-    // binning state of a pass lives in one allocation so that one memset clears it:
-    // [tile_count: vpp*n_tiles][survivor_count: vpp]
-    const size_t count_words = (size_t)vpp * n_tiles + vpp;
+    // per-tile counters of a pass, cleared by one memset; [block_count: vpp*n_blocks] follows and
+    // is fully written by the set-up kernel
+    const uint32_t n_blocks = (m->n_tris + 255u) / 256u;
+    const size_t count_words = (size_t)vpp * n_tiles;
     SR_HIP(dev->screen.ensure((size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex)));
-    SR_HIP(dev->tile_count.ensure(count_words * 4));
+    SR_HIP(dev->tile_count.ensure((count_words + (size_t)vpp * std::max(n_blocks, 1u)) * 4));
     SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
-    SR_HIP(dev->survivors.ensure((size_t)vpp * std::max<uint32_t>(m->n_tris, 1) * sizeof(uint2)));
+    SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * 256u * sizeof(uint2)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
     SR_HIP(dev->views.ensure((size_t)n_views * sizeof(ViewXform)));
     SR_HIP(dev->counters.ensure((size_t)passes * kCountersPerPass * 4));
@@ -200,7 +201,8 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
 
     BinBuffers b{};
     b.tile_count = (uint32_t*)dev->tile_count.ptr;
-    b.survivor_count = b.tile_count + (size_t)vpp * n_tiles;
+    b.block_count = b.tile_count + count_words;
+    b.n_blocks = n_blocks;
     b.tile_offset = (uint32_t*)dev->tile_offset.ptr;
     b.refs = (uint32_t*)dev->refs.ptr;
     b.ref_capacity = (uint32_t)dev->ref_capacity;

@@ -180,9 +180,10 @@ struct BinBuffers {
     uint32_t* tile_offset;    // [views*tiles + 1]: exclusive scan of tile_count
     uint32_t* refs;           // [capacity]: triangle ids grouped by (view, tile)
     uint32_t ref_capacity;
-    uint2* survivors;         // [views][max_tris]: {triangle id, packed tile range}
-    uint32_t* survivor_count; // [views]
-    uint32_t* counters;       // [4]: total refs, dropped refs, unprojectable triangles, spare
+    uint2* survivors;         // [views][blocks*256]: {triangle id, packed tile range}; set-up block b owns slots b*256..
+    uint32_t* block_count;    // [views][blocks]: survivors written by each set-up block
+    uint32_t n_blocks;        // set-up blocks per view = ceil(triangles / 256)
+    uint32_t* counters;       // [4]: total refs, dropped refs, unprojectable triangles, binned triangles
 };
 
 }  // namespace sr

@@ -48,16 +48,37 @@ __device__ inline ScreenVertex load_sv(const ScreenVertex* p)
 
 __device__ inline uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Block-local tile histogram in LDS: the 256 triangles of a block fall into a handful of tiles, so
+// the block adds to the global per-tile counters once per distinct tile instead of once per triangle.
+constexpr uint32_t kHashSize = 512;          // >= 2x the block size: never fills up
+constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
+__device__ inline uint32_t hash_slot(uint32_t* keys, uint32_t tile)
+{
+    uint32_t h = (tile * 2654435761u) >> 23;  // 9 bits
+    for (;;) {
+        const uint32_t old = atomicCAS(&keys[h], kHashEmpty, tile);
+        if (old == kHashEmpty || old == tile) return h;
+        h = (h + 1u) & (kHashSize - 1u);
+    }
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris,
                                                     const ScreenVertex* __restrict__ sv_all, uint32_t n_verts,
                                                     FrameGeom g, BinBuffers b)
 {
+    __shared__ uint32_t s_key[kHashSize];
+    __shared__ uint32_t s_cnt[kHashSize];
+    __shared__ uint32_t s_wave[4];
     const uint32_t view = blockIdx.y;
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t lane = lane_id();
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t = blockIdx.x * 256u + tid;
+    const uint32_t lane = lane_id(), wave = tid >> 6;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
     uint32_t* count = b.tile_count + (size_t)view * n_tiles;
+    s_key[tid] = kHashEmpty; s_key[tid + 256u] = kHashEmpty;
+    s_cnt[tid] = 0u; s_cnt[tid + 256u] = 0u;
+    __syncthreads();
 
     bool live = false, unproj = false;
     int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
@@ -86,40 +107,31 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
         const uint64_t m = __ballot(unproj);
         if (m && lane == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&b.counters[2], (uint32_t)__popcll(m));
     }
-    // per-tile counts: triangles inside one tile (the common case for small triangles) are
-    // aggregated over the wave, one atomic per distinct tile; larger ones add per tile
+    // per-tile counts: single-tile triangles go through the block histogram, larger ones add per tile
     const bool single = live && tx0 == tx1 && ty0 == ty1;
-    const uint32_t my_tile = (uint32_t)(ty0 * g.tiles_x + tx0);
-    {
-        bool pend = single;
-        uint64_t m = __ballot(pend);
-        while (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            const uint32_t lt = (uint32_t)__shfl((int)my_tile, leader);
-            const uint64_t same = __ballot(pend && my_tile == lt);
-            if (lane == (uint32_t)leader) atomicAdd(&count[lt], (uint32_t)__popcll(same));
-            if (my_tile == lt) pend = false;
-            m &= ~same;
-        }
-    }
+    if (single) atomicAdd(&s_cnt[hash_slot(s_key, (uint32_t)(ty0 * g.tiles_x + tx0))], 1u);
     if (live && !single) {
         for (int ty = ty0; ty <= ty1; ++ty)
             for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&count[ty * g.tiles_x + tx], 1u);
     }
-    // compaction of the survivors: ballot + prefix count, one atomic per wave
-    {
-        const uint64_t m = __ballot(live);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == (uint32_t)leader) base = atomicAdd(&b.survivor_count[view], (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (live) {
-                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                const uint32_t packed = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
-                b.survivors[(size_t)view * n_tris + base + rank] = make_uint2(t, packed);
-            }
-        }
+    // compaction of the survivors inside the block's own 256-slot segment: ballot + prefix counts
+    const uint64_t m = __ballot(live);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) { const uint32_t c = s_wave[w]; if (w < wave) base += c; total += c; }
+    if (live) {
+        const uint32_t rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t packed = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+        b.survivors[((size_t)view * b.n_blocks + blockIdx.x) * 256u + rank] = make_uint2(t, packed);
+    }
+    if (tid == 0) b.block_count[(size_t)view * b.n_blocks + blockIdx.x] = total;
+    // flush the histogram
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {
+        const uint32_t c = s_cnt[tid + 256u * k];
+        if (c) atomicAdd(&count[s_key[tid + 256u * k]], c);
     }
 }
 
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
 // stage 2b: exclusive scan of the per-tile counts (all views of the pass at once), one workgroup
 // =================================================================================================
 __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ offset,
-                                                    uint32_t* __restrict__ counters, const uint32_t* __restrict__ survivor_count, uint32_t n_views)
+                                                    uint32_t* __restrict__ counters, const uint32_t* __restrict__ block_count, uint32_t n_block_counts)
 {
     __shared__ uint32_t part[1024];
     const uint32_t tid = threadIdx.x;
@@ -146,59 +158,55 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
     uint32_t run = part[tid] - s;
     for (uint32_t i = beg; i < end; ++i) { offset[i] = run; run += count[i]; }
     if (tid == 1023u) { offset[n] = part[1023]; counters[0] = part[1023]; }
-    if (tid == 0u) {
-        uint32_t surv = 0;
-        for (uint32_t v = 0; v < n_views; ++v) surv += survivor_count[v];
-        counters[3] = surv;
-    }
+    // number of binned triangles (instrumentation)
+    uint32_t surv = 0;
+    for (uint32_t i = tid; i < n_block_counts; i += 1024u) surv += block_count[i];
+    for (int o = 32; o > 0; o >>= 1) surv += (uint32_t)__shfl_down((int)surv, o);
+    if ((tid & 63u) == 0u && surv) atomicAdd(&counters[3], surv);
 }
 
 // =================================================================================================
-// stage 2c: scatter the survivors into per-tile reference lists
+// stage 2c: scatter the survivors into per-tile reference lists.  Block b re-reads the survivors
+// set-up block b wrote; slots inside a tile's list are handed out once per (block, tile).
 // =================================================================================================
-__global__ __launch_bounds__(256) void fill_kernel(FrameGeom g, BinBuffers b, uint32_t n_tris)
+__global__ __launch_bounds__(256) void fill_kernel(FrameGeom g, BinBuffers b)
 {
-    const uint32_t view = blockIdx.y;
-    const uint32_t lane = lane_id();
+    __shared__ uint32_t s_key[kHashSize];
+    __shared__ uint32_t s_cnt[kHashSize];
+    const uint32_t view = blockIdx.y, tid = threadIdx.x;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
     uint32_t* count = b.tile_count + (size_t)view * n_tiles;
     const uint32_t* offset = b.tile_offset + (size_t)view * n_tiles;
-    const uint32_t n = b.survivor_count[view];
-    const uint2* surv = b.survivors + (size_t)view * n_tris;
-    const uint32_t stride = gridDim.x * 256u;
-    const uint32_t n_round = (n + 63u) & ~63u;   // whole waves take part in the ballots
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_round; i += stride) {
-        const bool have = i < n;
-        uint2 rec = make_uint2(0, 0);
-        if (have) rec = surv[i];
-        const int tx0 = rec.y & 255, ty0 = (rec.y >> 8) & 255, tx1 = (rec.y >> 16) & 255, ty1 = rec.y >> 24;
-        const bool single = have && tx0 == tx1 && ty0 == ty1;
-        const uint32_t my_tile = (uint32_t)(ty0 * g.tiles_x + tx0);
-        bool pend = single;
-        uint64_t m = __ballot(pend);
-        while (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            const uint32_t lt = (uint32_t)__shfl((int)my_tile, leader);
-            const uint64_t same = __ballot(pend && my_tile == lt);
-            uint32_t old = 0;
-            if (lane == (uint32_t)leader) old = atomicSub(&count[lt], (uint32_t)__popcll(same));
-            old = (uint32_t)__shfl((int)old, leader);
-            if (pend && my_tile == lt) {
-                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                const uint32_t pos = offset[lt] + old - 1u - rank;
+    const uint32_t n = b.block_count[(size_t)view * b.n_blocks + blockIdx.x];
+    if (n == 0) return;   // uniform over the block
+    s_key[tid] = kHashEmpty; s_key[tid + 256u] = kHashEmpty;
+    s_cnt[tid] = 0u; s_cnt[tid + 256u] = 0u;
+    __syncthreads();
+    const bool have = tid < n;
+    uint2 rec = make_uint2(0, 0);
+    if (have) rec = b.survivors[((size_t)view * b.n_blocks + blockIdx.x) * 256u + tid];
+    const int tx0 = rec.y & 255, ty0 = (rec.y >> 8) & 255, tx1 = (rec.y >> 16) & 255, ty1 = rec.y >> 24;
+    const bool single = have && tx0 == tx1 && ty0 == ty1;
+    uint32_t slot = 0, local = 0;
+    if (single) { slot = hash_slot(s_key, (uint32_t)(ty0 * g.tiles_x + tx0)); local = atomicAdd(&s_cnt[slot], 1u); }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {       // one global atomic per distinct tile of the block
+        const uint32_t e = tid + 256u * k, c = s_cnt[e];
+        if (c) { const uint32_t tile = s_key[e]; s_cnt[e] = offset[tile] + atomicSub(&count[tile], c) - c; }
+    }
+    __syncthreads();
+    if (single) {
+        const uint32_t pos = s_cnt[slot] + local;
+        if (pos < b.ref_capacity) b.refs[pos] = rec.x; else atomicAdd(&b.counters[1], 1u);
+    }
+    if (have && !single) {
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) {
+                const uint32_t tile = (uint32_t)(ty * g.tiles_x + tx);
+                const uint32_t pos = offset[tile] + atomicSub(&count[tile], 1u) - 1u;
                 if (pos < b.ref_capacity) b.refs[pos] = rec.x; else atomicAdd(&b.counters[1], 1u);
-                pend = false;
             }
-            m &= ~same;
-        }
-        if (have && !single) {
-            for (int ty = ty0; ty <= ty1; ++ty)
-                for (int tx = tx0; tx <= tx1; ++tx) {
-                    const uint32_t tile = (uint32_t)(ty * g.tiles_x + tx);
-                    const uint32_t pos = offset[tile] + atomicSub(&count[tile], 1u) - 1u;
-                    if (pos < b.ref_capacity) b.refs[pos] = rec.x; else atomicAdd(&b.counters[1], 1u);
-                }
-        }
     }
 }
 
@@ -686,14 +694,13 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views)
 {
-    scan_kernel<<<1, 1024, 0, st>>>(b.tile_count, n_entries, b.tile_offset, b.counters, b.survivor_count, n_views);
+    scan_kernel<<<1, 1024, 0, st>>>(b.tile_count, n_entries, b.tile_offset, b.counters, b.block_count, b.n_blocks * n_views);
 }
 
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views)
 {
     if (!n_tris || !n_views) return;
-    const uint32_t blocks = min(div_up(n_tris, 256), 2048u);
-    fill_kernel<<<dim3(blocks, n_views), 256, 0, st>>>(g, b, n_tris);
+    fill_kernel<<<dim3(b.n_blocks, n_views), 256, 0, st>>>(g, b);
 }
 
 void launch_raster(hipStream_t st, const uint32_t* idx, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g, const BinBuffers& b,
