@@ -132,7 +132,7 @@ int choose_tile_log2(const sr_device_t* dev, int samples)
 // per-view scratch bytes of a pass
 size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g)
 {
-    return (size_t)m->n_verts * sizeof(ScreenVertex) + ((size_t)m->n_tris + 256) * sizeof(uint2) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 8 + 64;
+    return (size_t)m->n_verts * sizeof(ScreenVertex) + ((size_t)m->n_tris + 1024) * 4 * sizeof(BinRecord) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 16 + 64;
 }
 
 uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views)
@@ -158,14 +158,15 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     if (dev->ref_capacity == 0) dev->ref_capacity = std::max<uint64_t>((uint64_t)m->n_tris * vpp, (uint64_t)1 << 20);
     dev->ref_capacity = std::min<uint64_t>(dev->ref_capacity, 0xFFFFFFFFull);
 
-    // per-tile counters of a pass, cleared by one memset; [block_count: vpp*n_blocks] follows and
-    // is fully written by the set-up kernel
-    const uint32_t n_blocks = (m->n_tris + 255u) / 256u;
-    const size_t count_words = (size_t)vpp * n_tiles;
+    // three per-tile counter arrays of a pass, cleared by one memset; [block_count: vpp*n_blocks]
+    // follows and is fully written by the set-up kernel
+    const uint32_t bt = setup_block_triangles();
+    const uint32_t n_blocks = (m->n_tris + bt - 1u) / bt;
+    const size_t count_words = (size_t)vpp * n_tiles * 3;
     SR_HIP(dev->screen.ensure((size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex)));
-    SR_HIP(dev->tile_count.ensure((count_words + (size_t)vpp * std::max(n_blocks, 1u)) * 4));
+    SR_HIP(dev->tile_count.ensure((count_words + 2 * (size_t)vpp * std::max(n_blocks, 1u)) * 4));
     SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
-    SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * 256u * sizeof(uint2)));
+    SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * setup_block_records() * sizeof(BinRecord)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
     SR_HIP(dev->views.ensure((size_t)n_views * sizeof(ViewXform)));
     SR_HIP(dev->counters.ensure((size_t)passes * kCountersPerPass * 4));
@@ -200,13 +201,23 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(hipMemsetAsync(dev->counters.ptr, 0, (size_t)passes * kCountersPerPass * 4, st));
 
     BinBuffers b{};
-    b.tile_count = (uint32_t*)dev->tile_count.ptr;
-    b.block_count = b.tile_count + count_words;
+    b.count_small = (uint32_t*)dev->tile_count.ptr;
+    b.count_large = b.count_small + (size_t)vpp * n_tiles;
+    b.cursor_large = b.count_large + (size_t)vpp * n_tiles;
+    b.block_count = b.count_small + count_words;
+    b.block_live = b.block_count + (size_t)vpp * std::max(n_blocks, 1u);
     b.n_blocks = n_blocks;
+    {   // stride close to the golden ratio of n_blocks and coprime with it
+        auto gcd = [](uint32_t a, uint32_t c) { while (c) { uint32_t t = a % c; a = c; c = t; } return a; };
+        uint32_t stride = (uint32_t)((double)n_blocks * 0.6180339887498949) | 1u;
+        while (n_blocks > 2 && gcd(stride, n_blocks) != 1u) stride += 2u;
+        b.block_stride = n_blocks > 2 ? stride % n_blocks : 1u;
+        if (b.block_stride == 0) b.block_stride = 1u;
+    }
     b.tile_offset = (uint32_t*)dev->tile_offset.ptr;
     b.refs = (uint32_t*)dev->refs.ptr;
     b.ref_capacity = (uint32_t)dev->ref_capacity;
-    b.survivors = (uint2*)dev->survivors.ptr;
+    b.records = (BinRecord*)dev->survivors.ptr;
 
     const sr_texture_t* albedo = tg->tex[0];
     const sr_texture_t* metallic = tg->tex[2];
@@ -220,7 +231,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[0], st));
         launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, (ScreenVertex*)dev->screen.ptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
-        SR_HIP(hipMemsetAsync(b.tile_count, 0, count_words * 4, st));
+        SR_HIP(hipMemsetAsync(b.count_small, 0, count_words * 4, st));
         launch_setup(st, m->d_idx, m->n_tris, (const ScreenVertex*)dev->screen.ptr, m->n_verts, g, b, nv);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
         launch_scan(st, b, nv * n_tiles, nv);

@@ -174,15 +174,29 @@ __device__ inline bool depth_key(const TriSetup& t, int64_t Ea, int64_t Eb, int6
     return true;
 }
 
-// launchers implemented by the stage files --------------------------------------------------------
+// binning records ---------------------------------------------------------------------------------
+struct BinRecord {            // 12 bytes, written by set-up, read by fill
+    uint32_t tri;             // triangle id
+    uint32_t where;           // small triangle: tile index; large triangle: tx0 | ty0<<8 | tx1<<16 | ty1<<24
+    uint32_t rel;             // small triangle: position inside the tile's list; large triangle: kLargeTri
+};
+constexpr uint32_t kLargeTri = 0xFFFFFFFFu;
+constexpr uint32_t kMaxSmallTiles = 4;   // a "small" triangle overlaps at most 2x2 tiles and gets one record per tile
+
 struct BinBuffers {
-    uint32_t* tile_count;     // [views][tiles]: triangles per tile, consumed by the fill pass
-    uint32_t* tile_offset;    // [views*tiles + 1]: exclusive scan of tile_count
+    // per (view, tile) counters, cleared before set-up: [3][views*tiles]
+    uint32_t* count_small;    // references of small triangles (positions handed out by set-up)
+    uint32_t* count_large;    // references of large triangles (appended after the small ones by fill)
+    uint32_t* cursor_large;   // fill-pass cursor of the large part
+    uint32_t* tile_offset;    // [views*tiles + 1]: exclusive scan of count_small + count_large
     uint32_t* refs;           // [capacity]: triangle ids grouped by (view, tile)
     uint32_t ref_capacity;
-    uint2* survivors;         // [views][blocks*256]: {triangle id, packed tile range}; set-up block b owns slots b*256..
-    uint32_t* block_count;    // [views][blocks]: survivors written by each set-up block
-    uint32_t n_blocks;        // set-up blocks per view = ceil(triangles / 256)
+    BinRecord* records;       // [views][blocks][block triangles * kMaxSmallTiles]; each set-up block owns one segment
+    uint32_t* block_count;    // [views][blocks]: records written by each set-up block
+    uint32_t* block_live;     // [views][blocks]: triangles that survived culling in each set-up block
+    uint32_t block_stride;    // coprime with n_blocks: hardware block i works on triangle block (i * block_stride) % n_blocks, so that
+                              // blocks running at the same time touch different tiles (their per-tile atomics do not pile up)
+    uint32_t n_blocks;        // set-up blocks per view
     uint32_t* counters;       // [4]: total refs, dropped refs, unprojectable triangles, binned triangles
 };
 

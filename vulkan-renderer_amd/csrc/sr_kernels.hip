@@ -48,18 +48,30 @@ __device__ inline ScreenVertex load_sv(const ScreenVertex* p)
 
 __device__ inline uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Block-local tile histogram in LDS: the 256 triangles of a block fall into a handful of tiles, so
-// the block adds to the global per-tile counters once per distinct tile instead of once per triangle.
-constexpr uint32_t kHashSize = 512;          // >= 2x the block size: never fills up
+// Binning.  Same-address global atomics are expensive (they serialise at the memory side), and a
+// coherent mesh makes neighbouring blocks hit the same few tiles at the same time.  So each block
+// first builds a histogram of its (triangle, tile) pairs in an LDS hash table, then reserves the
+// places of each group in the tile's list with ONE returning global atomic per distinct tile, and
+// writes one record per pair that already knows its final position.  The scan then only has to turn
+// per-tile totals into offsets and the fill pass is a plain scatter.
+constexpr uint32_t kTrisPerThread = 4;                       // independent loads in flight per lane
+constexpr uint32_t kBlockTris = 256u * kTrisPerThread;       // triangles per set-up block
+constexpr uint32_t kBlockRecords = kBlockTris * kMaxSmallTiles;
+constexpr uint32_t kHashBits = 11;
+constexpr uint32_t kHashSize = 1u << kHashBits;
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kHashProbes = 24;
+// slot of `tile` in the block's table, or kHashSize if the table is too crowded (the caller then
+// treats the triangle as a large one)
 __device__ inline uint32_t hash_slot(uint32_t* keys, uint32_t tile)
 {
-    uint32_t h = (tile * 2654435761u) >> 23;  // 9 bits
-    for (;;) {
+    uint32_t h = (tile * 2654435761u) >> (32 - kHashBits);
+    for (uint32_t p = 0; p < kHashProbes; ++p) {
         const uint32_t old = atomicCAS(&keys[h], kHashEmpty, tile);
         if (old == kHashEmpty || old == tile) return h;
         h = (h + 1u) & (kHashSize - 1u);
     }
+    return kHashSize;
 }
 
 template <int S>
@@ -69,84 +81,141 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
 {
     __shared__ uint32_t s_key[kHashSize];
     __shared__ uint32_t s_cnt[kHashSize];
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_total[2];   // records, live triangles
     const uint32_t view = blockIdx.y;
     const uint32_t tid = threadIdx.x;
-    const uint32_t t = blockIdx.x * 256u + tid;
-    const uint32_t lane = lane_id(), wave = tid >> 6;
+    const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * b.block_stride) % b.n_blocks);
+    const uint32_t lane = lane_id();
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
-    uint32_t* count = b.tile_count + (size_t)view * n_tiles;
-    s_key[tid] = kHashEmpty; s_key[tid + 256u] = kHashEmpty;
-    s_cnt[tid] = 0u; s_cnt[tid + 256u] = 0u;
+    uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
+    uint32_t* count_large = b.count_large + (size_t)view * n_tiles;
+#pragma unroll
+    for (uint32_t k = 0; k < kHashSize / 256u; ++k) { s_key[tid + 256u * k] = kHashEmpty; s_cnt[tid + 256u * k] = 0u; }
+    if (tid < 2) s_total[tid] = 0u;
     __syncthreads();
 
-    bool live = false, unproj = false;
-    int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
-    if (t < n_tris) {
-        const uint32_t i0 = idx[3 * (size_t)t], i1 = idx[3 * (size_t)t + 1], i2 = idx[3 * (size_t)t + 2];
-        const ScreenVertex* sv = sv_all + (size_t)view * n_verts;
-        const ScreenVertex v0 = load_sv(sv + i0), v1 = load_sv(sv + i1), v2 = load_sv(sv + i2);
-        TriSetup ts;
-        const int r = setup_triangle(v0, v1, v2, ts);
-        unproj = r == 2;
-        if (r == 1) {
+    // all index loads first, then all vertex loads: 12 independent gathers in flight per lane
+    const ScreenVertex* sv = sv_all + (size_t)view * n_verts;
+    uint32_t tri[kTrisPerThread], i0[kTrisPerThread], i1[kTrisPerThread], i2[kTrisPerThread];
+    bool in_range[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        tri[k] = blk * kBlockTris + k * 256u + tid;
+        in_range[k] = tri[k] < n_tris;
+        const uint32_t tt = in_range[k] ? tri[k] : 0u;
+        i0[k] = idx[3 * (size_t)tt]; i1[k] = idx[3 * (size_t)tt + 1]; i2[k] = idx[3 * (size_t)tt + 2];
+    }
+    int4 r0[kTrisPerThread], r1[kTrisPerThread], r2[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        r0[k] = *reinterpret_cast<const int4*>(sv + i0[k]);
+        r1[k] = *reinterpret_cast<const int4*>(sv + i1[k]);
+        r2[k] = *reinterpret_cast<const int4*>(sv + i2[k]);
+    }
+    // per triangle: number of records (0 = culled), tile span, and for small triangles the hash slot
+    // and the rank inside the slot's group for each covered tile
+    uint32_t nrec[kTrisPerThread], span[kTrisPerThread];
+    uint32_t slot[kTrisPerThread][kMaxSmallTiles], local[kTrisPerThread][kMaxSmallTiles];
+    uint32_t n_unproj = 0, n_live = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        nrec[k] = 0; span[k] = 0;
+        const int bad = (r0[k].w == 0) + (r1[k].w == 0) + (r2[k].w == 0);   // 1/w == +0.0f marks an unprojectable vertex
+        const int64_t area2 = (int64_t)(r1[k].x - r0[k].x) * (int64_t)(r2[k].y - r0[k].y) - (int64_t)(r2[k].x - r0[k].x) * (int64_t)(r1[k].y - r0[k].y);
+        if (in_range[k] && bad > 0 && bad < 3) ++n_unproj;
+        if (in_range[k] && bad == 0 && area2 < 0) {
             int x0, x1, y0, y1;
-            pixel_span<S>(ts.minX, ts.maxX, x0, x1);
-            pixel_span<S>(ts.minY, ts.maxY, y0, y1);
+            pixel_span<S>(min(r0[k].x, min(r1[k].x, r2[k].x)), max(r0[k].x, max(r1[k].x, r2[k].x)), x0, x1);
+            pixel_span<S>(min(r0[k].y, min(r1[k].y, r2[k].y)), max(r0[k].y, max(r1[k].y, r2[k].y)), y0, y1);
             x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
             y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
             if (x0 <= x1 && y0 <= y1) {
-                live = true;
-                tx0 = (x0 - g.rx) >> g.tile_log2; tx1 = (x1 - g.rx) >> g.tile_log2;
-                ty0 = (y0 - g.ry) >> g.tile_log2; ty1 = (y1 - g.ry) >> g.tile_log2;
+                ++n_live;
+                const int tx0 = (x0 - g.rx) >> g.tile_log2, tx1 = (x1 - g.rx) >> g.tile_log2;
+                const int ty0 = (y0 - g.ry) >> g.tile_log2, ty1 = (y1 - g.ry) >> g.tile_log2;
+                span[k] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+                const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
+                bool small = nx <= 2 && ny <= 2;
+                if (small) {
+                    nrec[k] = (uint32_t)(nx * ny);
+#pragma unroll
+                    for (uint32_t j = 0; j < kMaxSmallTiles; ++j) {
+                        slot[k][j] = kHashSize;
+                        if (j < nrec[k]) {
+                            const int tx = tx0 + (int)(j % (uint32_t)nx), ty = ty0 + (int)(j / (uint32_t)nx);
+                            slot[k][j] = hash_slot(s_key, (uint32_t)(ty * g.tiles_x + tx));
+                            if (slot[k][j] == kHashSize) small = false;
+                        }
+                    }
+                }
+                if (small) {
+#pragma unroll
+                    for (uint32_t j = 0; j < kMaxSmallTiles; ++j)
+                        if (j < nrec[k]) local[k][j] = atomicAdd(&s_cnt[slot[k][j]], 1u);
+                } else {
+                    nrec[k] = 1;
+                    slot[k][0] = kHashSize;   // marks the large-triangle record
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&count_large[ty * g.tiles_x + tx], 1u);
+                }
             }
         }
     }
-    // triangles that would need clipping: one add per wave
+    if (n_unproj) atomicAdd(&b.counters[2], n_unproj);   // triangles that would need clipping (rare)
+    // place of this lane's records inside the block's segment (any order will do)
+    uint32_t first[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) first[k] = nrec[k] ? atomicAdd(&s_total[0], nrec[k]) : 0u;
     {
-        const uint64_t m = __ballot(unproj);
-        if (m && lane == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&b.counters[2], (uint32_t)__popcll(m));
+        const uint64_t any = __ballot(n_live != 0);
+        uint32_t w = n_live;
+        for (int o = 32; o > 0; o >>= 1) w += (uint32_t)__shfl_down((int)w, o);
+        if (any && lane == 0) atomicAdd(&s_total[1], w);
     }
-    // per-tile counts: single-tile triangles go through the block histogram, larger ones add per tile
-    const bool single = live && tx0 == tx1 && ty0 == ty1;
-    if (single) atomicAdd(&s_cnt[hash_slot(s_key, (uint32_t)(ty0 * g.tiles_x + tx0))], 1u);
-    if (live && !single) {
-        for (int ty = ty0; ty <= ty1; ++ty)
-            for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&count[ty * g.tiles_x + tx], 1u);
-    }
-    // compaction of the survivors inside the block's own 256-slot segment: ballot + prefix counts
-    const uint64_t m = __ballot(live);
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    uint32_t base = 0, total = 0;
+    // one returning global atomic per distinct tile of the block reserves the group's place in the
+    // tile's list; the slot then holds the group's first position
 #pragma unroll
-    for (uint32_t w = 0; w < 4; ++w) { const uint32_t c = s_wave[w]; if (w < wave) base += c; total += c; }
-    if (live) {
-        const uint32_t rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        const uint32_t packed = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
-        b.survivors[((size_t)view * b.n_blocks + blockIdx.x) * 256u + rank] = make_uint2(t, packed);
+    for (uint32_t k = 0; k < kHashSize / 256u; ++k) {
+        const uint32_t e = tid + 256u * k, c = s_cnt[e];
+        if (c) s_cnt[e] = atomicAdd(&count_small[s_key[e]], c);
     }
-    if (tid == 0) b.block_count[(size_t)view * b.n_blocks + blockIdx.x] = total;
-    // flush the histogram
+    __syncthreads();
+    BinRecord* seg = b.records + ((size_t)view * b.n_blocks + blk) * kBlockRecords;
 #pragma unroll
-    for (uint32_t k = 0; k < 2; ++k) {
-        const uint32_t c = s_cnt[tid + 256u * k];
-        if (c) atomicAdd(&count[s_key[tid + 256u * k]], c);
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        if (nrec[k] == 0) continue;
+        if (slot[k][0] == kHashSize) {
+            BinRecord rec; rec.tri = tri[k]; rec.where = span[k]; rec.rel = kLargeTri;
+            seg[first[k]] = rec;
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < kMaxSmallTiles; ++j)
+                if (j < nrec[k]) {
+                    BinRecord rec; rec.tri = tri[k]; rec.where = s_key[slot[k][j]]; rec.rel = s_cnt[slot[k][j]] + local[k][j];
+                    seg[first[k] + j] = rec;
+                }
+        }
+    }
+    if (tid == 0) {
+        b.block_count[(size_t)view * b.n_blocks + blk] = s_total[0];
+        b.block_live[(size_t)view * b.n_blocks + blk] = s_total[1];
     }
 }
 
 // =================================================================================================
 // stage 2b: exclusive scan of the per-tile counts (all views of the pass at once), one workgroup
 // =================================================================================================
-__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ offset,
-                                                    uint32_t* __restrict__ counters, const uint32_t* __restrict__ block_count, uint32_t n_block_counts)
+__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ count_a, const uint32_t* __restrict__ count_b, uint32_t n,
+                                                    uint32_t* __restrict__ offset, uint32_t* __restrict__ counters,
+                                                    const uint32_t* __restrict__ block_live, uint32_t n_block_counts)
 {
     __shared__ uint32_t part[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t beg = min(tid * per, n), end = min(beg + per, n);
     uint32_t s = 0;
-    for (uint32_t i = beg; i < end; ++i) s += count[i];
+    for (uint32_t i = beg; i < end; ++i) s += count_a[i] + count_b[i];
     part[tid] = s;
     __syncthreads();
     for (uint32_t d = 1; d < 1024u; d <<= 1) {   // Hillis-Steele inclusive scan
@@ -156,57 +225,43 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
         __syncthreads();
     }
     uint32_t run = part[tid] - s;
-    for (uint32_t i = beg; i < end; ++i) { offset[i] = run; run += count[i]; }
+    for (uint32_t i = beg; i < end; ++i) { offset[i] = run; run += count_a[i] + count_b[i]; }
     if (tid == 1023u) { offset[n] = part[1023]; counters[0] = part[1023]; }
     // number of binned triangles (instrumentation)
     uint32_t surv = 0;
-    for (uint32_t i = tid; i < n_block_counts; i += 1024u) surv += block_count[i];
+    for (uint32_t i = tid; i < n_block_counts; i += 1024u) surv += block_live[i];
     for (int o = 32; o > 0; o >>= 1) surv += (uint32_t)__shfl_down((int)surv, o);
     if ((tid & 63u) == 0u && surv) atomicAdd(&counters[3], surv);
 }
 
 // =================================================================================================
-// stage 2c: scatter the survivors into per-tile reference lists.  Block b re-reads the survivors
-// set-up block b wrote; slots inside a tile's list are handed out once per (block, tile).
+// stage 2c: scatter the records into per-tile reference lists.  Small triangles already know their
+// place (tile offset + position reserved by set-up): a plain scatter.  Large triangles are appended
+// behind them, one atomic per covered tile.
 // =================================================================================================
 __global__ __launch_bounds__(256) void fill_kernel(FrameGeom g, BinBuffers b)
 {
-    __shared__ uint32_t s_key[kHashSize];
-    __shared__ uint32_t s_cnt[kHashSize];
     const uint32_t view = blockIdx.y, tid = threadIdx.x;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
-    uint32_t* count = b.tile_count + (size_t)view * n_tiles;
     const uint32_t* offset = b.tile_offset + (size_t)view * n_tiles;
+    const uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
+    uint32_t* cursor_large = b.cursor_large + (size_t)view * n_tiles;
     const uint32_t n = b.block_count[(size_t)view * b.n_blocks + blockIdx.x];
-    if (n == 0) return;   // uniform over the block
-    s_key[tid] = kHashEmpty; s_key[tid + 256u] = kHashEmpty;
-    s_cnt[tid] = 0u; s_cnt[tid + 256u] = 0u;
-    __syncthreads();
-    const bool have = tid < n;
-    uint2 rec = make_uint2(0, 0);
-    if (have) rec = b.survivors[((size_t)view * b.n_blocks + blockIdx.x) * 256u + tid];
-    const int tx0 = rec.y & 255, ty0 = (rec.y >> 8) & 255, tx1 = (rec.y >> 16) & 255, ty1 = rec.y >> 24;
-    const bool single = have && tx0 == tx1 && ty0 == ty1;
-    uint32_t slot = 0, local = 0;
-    if (single) { slot = hash_slot(s_key, (uint32_t)(ty0 * g.tiles_x + tx0)); local = atomicAdd(&s_cnt[slot], 1u); }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < 2; ++k) {       // one global atomic per distinct tile of the block
-        const uint32_t e = tid + 256u * k, c = s_cnt[e];
-        if (c) { const uint32_t tile = s_key[e]; s_cnt[e] = offset[tile] + atomicSub(&count[tile], c) - c; }
-    }
-    __syncthreads();
-    if (single) {
-        const uint32_t pos = s_cnt[slot] + local;
-        if (pos < b.ref_capacity) b.refs[pos] = rec.x; else atomicAdd(&b.counters[1], 1u);
-    }
-    if (have && !single) {
-        for (int ty = ty0; ty <= ty1; ++ty)
-            for (int tx = tx0; tx <= tx1; ++tx) {
-                const uint32_t tile = (uint32_t)(ty * g.tiles_x + tx);
-                const uint32_t pos = offset[tile] + atomicSub(&count[tile], 1u) - 1u;
-                if (pos < b.ref_capacity) b.refs[pos] = rec.x; else atomicAdd(&b.counters[1], 1u);
-            }
+    const BinRecord* seg = b.records + ((size_t)view * b.n_blocks + blockIdx.x) * kBlockRecords;
+    for (uint32_t i = tid; i < n; i += 256u) {
+        const BinRecord rec = seg[i];
+        if (rec.rel != kLargeTri) {
+            const uint32_t pos = offset[rec.where] + rec.rel;
+            if (pos < b.ref_capacity) b.refs[pos] = rec.tri; else atomicAdd(&b.counters[1], 1u);
+        } else {
+            const int tx0 = rec.where & 255, ty0 = (rec.where >> 8) & 255, tx1 = (rec.where >> 16) & 255, ty1 = rec.where >> 24;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    const uint32_t tile = (uint32_t)(ty * g.tiles_x + tx);
+                    const uint32_t pos = offset[tile] + count_small[tile] + atomicAdd(&cursor_large[tile], 1u);
+                    if (pos < b.ref_capacity) b.refs[pos] = rec.tri; else atomicAdd(&b.counters[1], 1u);
+                }
+        }
     }
 }
 
@@ -687,14 +742,14 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
                   const BinBuffers& b, uint32_t n_views)
 {
     if (!n_tris || !n_views) return;
-    const dim3 grid(div_up(n_tris, 256), n_views);
+    const dim3 grid(b.n_blocks, n_views);
     if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sv, n_verts, g, b);
     else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sv, n_verts, g, b);
 }
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views)
 {
-    scan_kernel<<<1, 1024, 0, st>>>(b.tile_count, n_entries, b.tile_offset, b.counters, b.block_count, b.n_blocks * n_views);
+    scan_kernel<<<1, 1024, 0, st>>>(b.count_small, b.count_large, n_entries, b.tile_offset, b.counters, b.block_live, b.n_blocks * n_views);
 }
 
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views)
@@ -718,6 +773,9 @@ void launch_raster(hipStream_t st, const uint32_t* idx, const ScreenVertex* sv, 
     else if (g.samples == 4 && g.tile_log2 == 4)
         raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
 }
+
+uint32_t setup_block_triangles() { return kBlockTris; }
+uint32_t setup_block_records() { return kBlockRecords; }
 
 bool raster_config_supported(int samples, int tile_log2)
 {

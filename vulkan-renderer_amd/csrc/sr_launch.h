@@ -28,6 +28,8 @@ void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32
 void launch_raster(hipStream_t st, const uint32_t* idx, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g, const BinBuffers& b,
                    uint64_t* vis, uint32_t view0, uint32_t n_views);
 bool raster_config_supported(int samples, int tile_log2);
+uint32_t setup_block_triangles();   // triangles handled by one set-up block
+uint32_t setup_block_records();     // size of the record segment one set-up block owns
 void launch_fragment(hipStream_t st, const FragLaunch& f);
 void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh);
 void launch_split_vis(hipStream_t st, const uint64_t* vis, size_t n, float* depth, uint32_t* tri);
