@@ -241,7 +241,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         launch_raster(st, m->d_idx, (const ScreenVertex*)dev->screen.ptr, m->n_verts, g, b, tg->d_vis, v0, nv);
         if (ev) SR_HIP(hipEventRecord(ev[5], st));
         FragLaunch f{};
-        f.idx = m->d_idx; f.verts_aos = m->d_aos; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
+        f.idx = m->d_idx; f.verts_aos = m->d_aos; f.screen = (const ScreenVertex*)dev->screen.ptr; f.n_verts = m->n_verts; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv;
         launch_fragment(st, f);

@@ -292,6 +292,29 @@ __device__ inline void raster_pixel(const TriSetup& ts, uint32_t tri, int x, int
     }
 }
 
+// Same arithmetic in 32 bits, valid when the triangle's bounding box is under 64 pixels on both axes:
+// every factor is then below 2^15 + 2^9 and every edge function below 2^31, so the integers (and the
+// floats converted from them) are the same as in the 64-bit form.
+__device__ inline bool fits_32bit(const TriSetup& ts) { return (ts.maxX - ts.minX) < 16384 && (ts.maxY - ts.minY) < 16384; }
+
+template <int S>
+__device__ inline void raster_pixel32(const TriSetup& ts, uint32_t tri, int x, int y, unsigned long long* cell /* S words */)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int32_t px = x * kSubpix + sample_dx(S, s), py = y * kSubpix + sample_dy(S, s);
+        const int32_t Ea = (ts.cx - ts.bx) * (py - ts.by) - (ts.cy - ts.by) * (px - ts.bx);
+        const int32_t Eb = (ts.ax - ts.cx) * (py - ts.cy) - (ts.ay - ts.cy) * (px - ts.cx);
+        const int32_t Ec = (ts.bx - ts.ax) * (py - ts.ay) - (ts.by - ts.ay) * (px - ts.ax);
+        if (((Ea + ts.bias_a) | (Eb + ts.bias_b) | (Ec + ts.bias_c)) < 0) continue;
+        const float l0 = (float)Ea * ts.rA, l2 = (float)Eb * ts.rA, l1 = (float)Ec * ts.rA;
+        float z = fmaf(l2, ts.z2, fmaf(l1, ts.z1, l0 * ts.z0));
+        z = z + 0.0f;
+        if (!(z >= 0.0f && z <= 1.0f)) continue;
+        atomicMin(cell + s, ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
+    }
+}
+
 template <int TL2, int S, int TPB>
 __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict__ idx, const ScreenVertex* __restrict__ sv_all, uint32_t n_verts,
                                                      FrameGeom g, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ refs,
@@ -335,9 +358,15 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
             }
         }
         if (have && npix <= kSmall) {
-            for (int y = L.y0; y <= L.y1; ++y)
-                for (int x = L.x0; x <= L.x1; ++x)
-                    raster_pixel<S>(L.ts, L.tri, x, y, &tile[((y - py0) * T + (x - px0)) * S]);
+            if (fits_32bit(L.ts)) {
+                for (int y = L.y0; y <= L.y1; ++y)
+                    for (int x = L.x0; x <= L.x1; ++x)
+                        raster_pixel32<S>(L.ts, L.tri, x, y, &tile[((y - py0) * T + (x - px0)) * S]);
+            } else {
+                for (int y = L.y0; y <= L.y1; ++y)
+                    for (int x = L.x0; x <= L.x1; ++x)
+                        raster_pixel<S>(L.ts, L.tri, x, y, &tile[((y - py0) * T + (x - px0)) * S]);
+            }
         }
         uint64_t big = __ballot(have && npix > kSmall);
         while (big) {
@@ -352,11 +381,15 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
             ts.rA = __shfl(L.ts.rA, src);
             const int x0 = __shfl(L.x0, src), x1 = __shfl(L.x1, src), y0 = __shfl(L.y0, src), y1 = __shfl(L.y1, src);
             const uint32_t tri = (uint32_t)__shfl((int)L.tri, src);
+            const bool narrow = __shfl((int)fits_32bit(L.ts), src) != 0;
             const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
             for (int by = y0; by <= y1; by += 8)
                 for (int bx = x0; bx <= x1; bx += 8) {
                     const int x = bx + lx, y = by + ly;
-                    if (x <= x1 && y <= y1) raster_pixel<S>(ts, tri, x, y, &tile[((y - py0) * T + (x - px0)) * S]);
+                    if (x <= x1 && y <= y1) {
+                        if (narrow) raster_pixel32<S>(ts, tri, x, y, &tile[((y - py0) * T + (x - px0)) * S]);
+                        else raster_pixel<S>(ts, tri, x, y, &tile[((y - py0) * T + (x - px0)) * S]);
+                    }
                 }
         }
     }
@@ -459,88 +492,90 @@ __device__ inline void sample_texture(const TexDesc& t, float s, float tt, float
     for (int c = 0; c < NCH; ++c) o[c] = (1.0f - delta) * chi[c] + delta * clo[c];
 }
 
+// Colour arithmetic below is allowed 1 LSB of the 8-bit result against the CPU oracle, so it uses
+// the hardware reciprocal / reciprocal-square-root / exp2 / log2 (1 ulp) instead of IEEE division.
+// Nothing here feeds coverage, depth or triangle ids.
 __device__ inline float max0(float x) { return x > 0.0f ? x : 0.0f; }
-__device__ inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline float dot3(const float* a, const float* b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
 __device__ inline void normalize3(const float* a, float* o)
 {
-    const float inv = 1.0f / sqrtf(dot3(a, a));
+    const float inv = frsq(dot3(a, a));
     o[0] = a[0] * inv; o[1] = a[1] * inv; o[2] = a[2] * inv;
 }
 __device__ inline float fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }   // pow() of the shader; x >= 0
 
 __device__ inline float geometry_schlick_ggx(float NdotV, float roughness)
 {
-    const float r = roughness + 1.0f, k = (r * r) / 8.0f;
-    return NdotV / (NdotV * (1.0f - k) + k);
+    const float r = roughness + 1.0f, k = (r * r) * 0.125f;
+    return NdotV * frcp(fmaf(NdotV, 1.0f - k, k));
 }
 
 // main() of shaders/shader.frag with the three texture() results passed in
 __device__ inline void fragment_main(const float* wp, const float* N, const float* cam, const float* albedo_tex,
                                      float metallic, float roughness, float* out)
 {
-    const float kPI = 3.14159265359f;
+    const float kPI = 3.14159265359f, kInvPI = 1.0f / 3.14159265359f;
     const float albedo[3] = { fast_pow(albedo_tex[0], 2.2f), fast_pow(albedo_tex[1], 2.2f), fast_pow(albedo_tex[2], 2.2f) };
     const float ao = 0.01f;
     float V[3], t[3];
     t[0] = cam[0] - wp[0]; t[1] = cam[1] - wp[1]; t[2] = cam[2] - wp[2];
     normalize3(t, V);
-    float F0[3];
+    float F0[3], diff[3];
+    const float one_m = 1.0f - metallic;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) F0[c] = 0.04f * (1.0f - metallic) + albedo[c] * metallic;
+    for (int c = 0; c < 3; ++c) { F0[c] = fmaf(albedo[c], metallic, 0.04f * one_m); diff[c] = albedo[c] * kInvPI * one_m; }
     float Lo[3] = { 0.0f, 0.0f, 0.0f };
     const float power[3] = { 23.47f, 21.31f, 20.79f };
     const float NdotV = max0(dot3(N, V));
     const float a = roughness * roughness, a2 = a * a;
+    const float gv = geometry_schlick_ggx(NdotV, roughness);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float lp[3] = { (i & 1) ? 10.0f : -10.0f, (i & 2) ? -10.0f : 10.0f, 10.0f };
-        float D[3] = { lp[0] - wp[0], lp[1] - wp[1], lp[2] - wp[2] };
+        const float D[3] = { lp[0] - wp[0], lp[1] - wp[1], lp[2] - wp[2] };
         float L[3], Hv[3];
-        normalize3(D, L);
+        const float dd = dot3(D, D);
+        const float invd = frsq(dd);
+        L[0] = D[0] * invd; L[1] = D[1] * invd; L[2] = D[2] * invd;
         t[0] = V[0] + L[0]; t[1] = V[1] + L[1]; t[2] = V[2] + L[2];
         normalize3(t, Hv);
-        const float attenuation = 1.0f / dot3(D, D);
+        const float attenuation = invd * invd;           // 1 / dot(D, D)
         const float NdotH = max0(dot3(N, Hv)), NdotH2 = NdotH * NdotH;
-        float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
+        float denom = fmaf(NdotH2, a2 - 1.0f, 1.0f);
         denom = kPI * denom * denom;
-        const float NDF = a2 / denom;
+        const float NDF = a2 * frcp(denom);
         const float NdotL = max0(dot3(N, L));
-        const float G = geometry_schlick_ggx(NdotL, roughness) * geometry_schlick_ggx(NdotV, roughness);
-        const float fc = fast_pow(1.0f - max0(dot3(Hv, V)), 5.0f);
-        const float denominator = 4.0f * NdotV * NdotL + 0.001f;
-        const float dn = denominator > 0.001f ? denominator : 0.001f;
+        const float G = geometry_schlick_ggx(NdotL, roughness) * gv;
+        const float x1 = 1.0f - max0(dot3(Hv, V));
+        const float x2 = x1 * x1;
+        const float fc = x2 * x2 * x1;                    // pow(x, 5.0)
+        const float denominator = fmaf(4.0f * NdotV, NdotL, 0.001f);
+        const float rdn = frcp(denominator > 0.001f ? denominator : 0.001f);
+        const float ndg = NDF * G * rdn;
+        const float att_ndl = attenuation * NdotL;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float F = F0[c] + (1.0f - F0[c]) * fc;
-            const float specular = (NDF * G * F) / dn;
-            const float kD = (1.0f - F) * (1.0f - metallic);
-            const float radiance = power[c] * attenuation;
-            Lo[c] += (kD * albedo[c] / kPI + specular) * radiance * NdotL;
+            const float F = fmaf(1.0f - F0[c], fc, F0[c]);
+            const float radiance = power[c] * att_ndl;
+            Lo[c] = fmaf(fmaf(1.0f - F, diff[c], ndg * F), radiance, Lo[c]);   // (kD*albedo/PI + specular) * radiance * NdotL
         }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float ambient = 0.03f * albedo[c] * ao;
         float color = ambient + Lo[c];
-        color = color / (color + 1.0f);
+        color = color * frcp(color + 1.0f);
         out[c] = fast_pow(color, 1.0f / 2.2f);
     }
 }
 
-__device__ inline void persp_weights(const TriSetup& t, float rw0, float rw1, float rw2, int64_t px, int64_t py, float& p0, float& p1, float& p2)
-{
-    int64_t Ea, Eb, Ec;
-    edge_eval(t, px, py, Ea, Eb, Ec);
-    const float l0 = (float)Ea * t.rA, l2 = (float)Eb * t.rA, l1 = (float)Ec * t.rA;
-    const float q0 = l0 * rw0, q1 = l1 * rw1, q2 = l2 * rw2;
-    const float rden = 1.0f / ((q0 + q1) + q2);
-    p0 = q0 * rden; p1 = q1 * rden; p2 = q2 * rden;
-}
-__device__ inline float interp(float p0, float p1, float p2, float a0, float a1, float a2) { return fmaf(p2, a2, fmaf(p1, a1, p0 * a0)); }
-
 struct FragParams {
     const uint32_t* idx;
     const float4* verts;       // 2 float4 per vertex: (pos.xyz, n.x) (n.yz, uv)
+    const ScreenVertex* screen; // window-space vertices of the views of this pass, [views][n_verts]
+    uint32_t n_verts;
     const ViewXform* views;    // views of this pass
     const unsigned long long* vis;
     uint32_t* color;
@@ -550,22 +585,46 @@ struct FragParams {
     uint32_t view0;            // first view of this pass inside the target
 };
 
-// shades triangle `tri` at pixel (x,y): packed B,G,R,A
-__device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, uint32_t tri, int x, int y, const float* dec, const float* thr)
+// shades triangle `tri` at pixel (x,y): packed B,G,R,A.  Barycentrics are evaluated in float relative
+// to vertex 0 (exact for triangles up to a few hundred pixels, 2^-24 relative otherwise); the values
+// at the other pixels of the 2x2 quad follow from their screen-space gradients.
+__device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, const ScreenVertex* sv, uint32_t tri, int x, int y,
+                                       const float* dec, const float* thr)
 {
     const uint32_t i0 = p.idx[3 * (size_t)tri], i1 = p.idx[3 * (size_t)tri + 1], i2 = p.idx[3 * (size_t)tri + 2];
     const float4 a0 = p.verts[2 * (size_t)i0], b0 = p.verts[2 * (size_t)i0 + 1];
     const float4 a1 = p.verts[2 * (size_t)i1], b1 = p.verts[2 * (size_t)i1 + 1];
     const float4 a2 = p.verts[2 * (size_t)i2], b2 = p.verts[2 * (size_t)i2 + 1];
-    float clip[4];
-    // recomputing the window-space vertices gives bit-identical values to the vertex stage
-    const ScreenVertex v0 = project_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H, clip);
-    const ScreenVertex v1 = project_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H, clip);
-    const ScreenVertex v2 = project_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H, clip);
-    TriSetup ts;
-    setup_triangle(v0, v1, v2, ts);
-    float p0, p1, p2;
-    persp_weights(ts, v0.rw, v1.rw, v2.rw, (int64_t)x * kSubpix + kHalf, (int64_t)y * kSubpix + kHalf, p0, p1, p2);
+    const ScreenVertex v0 = load_sv(sv + i0), v1 = load_sv(sv + i1), v2 = load_sv(sv + i2);
+    // edge vectors relative to v0, 1/256 pixel; weights: l1 = cross(p - v0, e2) / A', l2 = cross(e1, p - v0) / A'
+    const float e1x = (float)(v1.X - v0.X), e1y = (float)(v1.Y - v0.Y);
+    const float e2x = (float)(v2.X - v0.X), e2y = (float)(v2.Y - v0.Y);
+    const float dx = (float)(x * kSubpix + kHalf - v0.X), dy = (float)(y * kSubpix + kHalf - v0.Y);
+    const float rA = frcp(e1x * e2y - e1y * e2x);
+    const float l1 = (dx * e2y - dy * e2x) * rA, l2 = (e1x * dy - e1y * dx) * rA, l0 = 1.0f - l1 - l2;
+    // gradients per pixel step (256 sub-pixels)
+    const float s = (float)kSubpix * rA;
+    const float l1x = e2y * s, l1y = -e2x * s, l2x = -e1y * s, l2y = e1x * s;
+    // perspective: attribute = sum(q_i a_i) / sum(q_i), q_i = l_i / w_i, all affine in screen space
+    const float q0 = l0 * v0.rw, q1 = l1 * v1.rw, q2 = l2 * v2.rw;
+    const float q0x = -(l1x + l2x) * v0.rw, q1x = l1x * v1.rw, q2x = l2x * v2.rw;
+    const float q0y = -(l1y + l2y) * v0.rw, q1y = l1y * v1.rw, q2y = l2y * v2.rw;
+    const float D = q0 + q1 + q2, Dx = q0x + q1x + q2x, Dy = q0y + q1y + q2y;
+    const float Nu = fmaf(q2, b2.z, fmaf(q1, b1.z, q0 * b0.z)), Nv = fmaf(q2, b2.w, fmaf(q1, b1.w, q0 * b0.w));
+    const float Nux = fmaf(q2x, b2.z, fmaf(q1x, b1.z, q0x * b0.z)), Nvx = fmaf(q2x, b2.w, fmaf(q1x, b1.w, q0x * b0.w));
+    const float Nuy = fmaf(q2y, b2.z, fmaf(q1y, b1.z, q0y * b0.z)), Nvy = fmaf(q2y, b2.w, fmaf(q1y, b1.w, q0y * b0.w));
+    const float rD = frcp(D);
+    const float u = Nu * rD, v = Nv * rD;
+    const float p0 = q0 * rD, p1 = q1 * rD, p2 = q2 * rD;
+    // coarse derivatives over the pixel's 2x2 quad: this triangle's uv at the quad's top-left,
+    // top-right and bottom-left pixel centres (what helper invocations would compute)
+    const float ox = (float)((x & ~1) - x), oy = (float)((y & ~1) - y);
+    const float D00 = fmaf(oy, Dy, fmaf(ox, Dx, D)), Nu00 = fmaf(oy, Nuy, fmaf(ox, Nux, Nu)), Nv00 = fmaf(oy, Nvy, fmaf(ox, Nvx, Nv));
+    const float r00 = frcp(D00), r10 = frcp(D00 + Dx), r01 = frcp(D00 + Dy);
+    const float u00 = Nu00 * r00, v00 = Nv00 * r00;
+    const float dudx = (Nu00 + Nux) * r10 - u00, dvdx = (Nv00 + Nvx) * r10 - v00;
+    const float dudy = (Nu00 + Nuy) * r01 - u00, dvdy = (Nv00 + Nvy) * r01 - v00;
+
     float w0[4], w1[4], w2[4], n0[3], n1[3], n2[3];
     mat4_mul_vec4(vx.model, a0.x, a0.y, a0.z, 1.0f, w0);
     mat4_mul_vec4(vx.model, a1.x, a1.y, a1.z, 1.0f, w1);
@@ -575,20 +634,7 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     mat3_mul_vec3(vx.model, a2.w, b2.x, b2.y, n2);
     float wp[3], N[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { wp[k] = interp(p0, p1, p2, w0[k], w1[k], w2[k]); N[k] = interp(p0, p1, p2, n0[k], n1[k], n2[k]); }
-    const float u = interp(p0, p1, p2, b0.z, b1.z, b2.z), v = interp(p0, p1, p2, b0.w, b1.w, b2.w);
-    // coarse derivatives over the pixel's 2x2 quad, evaluated for this triangle at the quad's
-    // top-left, top-right and bottom-left pixel centres (what helper invocations would compute)
-    const int qx = x & ~1, qy = y & ~1;
-    float uq[3], vq[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float r0, r1, r2;
-        persp_weights(ts, v0.rw, v1.rw, v2.rw, (int64_t)(qx + (k == 1)) * kSubpix + kHalf, (int64_t)(qy + (k == 2)) * kSubpix + kHalf, r0, r1, r2);
-        uq[k] = interp(r0, r1, r2, b0.z, b1.z, b2.z);
-        vq[k] = interp(r0, r1, r2, b0.w, b1.w, b2.w);
-    }
-    const float dudx = uq[1] - uq[0], dvdx = vq[1] - vq[0], dudy = uq[2] - uq[0], dvdy = vq[2] - vq[0];
+    for (int k = 0; k < 3; ++k) { wp[k] = fmaf(p2, w2[k], fmaf(p1, w1[k], p0 * w0[k])); N[k] = fmaf(p2, n2[k], fmaf(p1, n1[k], p0 * n0[k])); }
     float alb[3], met[1], rgh[1], rgb[3];
     sample_texture<3>(p.albedo, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
     sample_texture<1>(p.metallic, u, v, dudx, dvdx, dudy, dvdy, dec, met);
@@ -616,6 +662,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
     const unsigned long long* v = p.vis + pix * S;
     const int x = p.g.rx + lx, y = p.g.ry + ly;
     const ViewXform& vx = p.views[view];
+    const ScreenVertex* sv = p.screen + (size_t)view * p.n_verts;
     uint32_t ids[S], col[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) ids[s] = (uint32_t)v[s];
@@ -631,7 +678,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
             for (int k = 0; k < s; ++k) if (k == prev) c = col[k];
             col[s] = c;
         } else {
-            col[s] = shade_pixel(p, vx, ids[s], x, y, s_dec, s_thr);
+            col[s] = shade_pixel(p, vx, sv, ids[s], x, y, s_dec, s_thr);
         }
     }
     uint32_t outc;
@@ -786,7 +833,7 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
 {
     if (!f.n_views) return;
     FragParams p;
-    p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
+    p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.screen = f.screen; p.n_verts = f.n_verts; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
     p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness;
     p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0;
     const dim3 grid(div_up((uint32_t)f.g.rw, 32), div_up((uint32_t)f.g.rh, 8), f.n_views), block(32, 8);

@@ -8,6 +8,8 @@ namespace sr {
 struct FragLaunch {
     const uint32_t* idx;
     const void* verts_aos;     // the reference's 32-byte vertex records
+    const ScreenVertex* screen; // window-space vertices of this pass, [views][n_verts]
+    uint32_t n_verts;
     const ViewXform* views;
     const uint64_t* vis;
     uint32_t* color;
