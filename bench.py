@@ -38,6 +38,7 @@ def stage_bytes(V, T, R, F, P, Pv, S, survivors):
     stage that must touch it.  X (unique texels over the three maps) is modelled as Pv*3*1.33."""
     X = Pv * 3 * 1.33
     return {
+        "clear": P * S * 8,
         "vertex": V * 12 + V * 16,
         "setup": T * 12 + V * 16 + survivors * 8,
         "scan": 0,
@@ -124,7 +125,7 @@ def main():
         frames_per_s = world * args.steps / elapsed
         mtris = T * frames_per_s / 1e6
         by = stage_bytes(V, T, R, F, P, Pv, 1, surv)
-        kernels = {k: stage_ms[k + "_ms"] for k in ("vertex", "setup", "scan", "fill", "raster", "fragment")}
+        kernels = {k: stage_ms[k + "_ms"] for k in ("clear", "vertex", "setup", "scan", "fill", "raster", "fragment")}
         dom = max(kernels, key=kernels.get)
         achieved = by[dom] / (kernels[dom] * 1e-3) / 1e9
         traffic = None
@@ -144,7 +145,7 @@ def main():
                        "views_per_gpu": 1, "sharding": "by view (no collective)" if world > 1 else "single GPU"},
             "frames_per_s": round(frames_per_s, 2),
             "gpixels_shaded_per_s": round(shaded_total * args.steps / elapsed / 1e9, 4),
-            "counters": {"V": V, "T": T, "R": R, "F": F, "P": P, "Pv": Pv, "S": 1, "survivors": surv},
+            "counters": {"V": V, "T": T, "R": R, "F": F, "P": P, "Pv": Pv, "S": 1, "binned": surv, "direct": stats["triangles_direct"]},
             "kernel_ms": {k: round(v, 4) for k, v in kernels.items()},
             "frame_algorithmic_bytes": int(frame_bytes),
             "frame_hbm_fraction": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -61,17 +61,18 @@ typedef enum sr_readback_kind {
 typedef struct sr_draw_stats {
     uint64_t vertices;            /* V: vertices transformed */
     uint64_t triangles;           /* T: triangles submitted */
-    uint64_t triangles_binned;    /* front-facing triangles that cover at least one tile */
-    uint64_t tile_refs;           /* R: (triangle, tile) references emitted */
+    uint64_t triangles_binned;    /* surviving triangles that went through the per-tile lists */
+    uint64_t tile_refs;           /* (triangle, tile) references emitted for them */
     uint64_t triangles_unprojectable; /* dropped: a vertex at w <= 0 or outside the guard band */
     uint64_t shaded_pixels;       /* Pv: pixels with at least one covered sample */
     uint64_t visible_triangles;   /* F: distinct triangles owning at least one sample */
     uint64_t pixels;              /* P: pixels of the stored rectangle */
+    uint64_t triangles_direct;    /* micro-triangles resolved by the set-up kernel itself (they cover >= 1 sample) */
 } sr_draw_stats;
 
 /* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */
 typedef struct sr_stage_times {
-    float vertex_ms, setup_ms, scan_ms, fill_ms, raster_ms, fragment_ms, total_ms;
+    float clear_ms, vertex_ms, setup_ms, scan_ms, fill_ms, raster_ms, fragment_ms, total_ms;
 } sr_stage_times;
 
 /* ---- device: replaces vkh::GPUDevice, src/vulkan_helper/gpu_device.hpp:42-48 (constructed at

@@ -46,8 +46,8 @@ struct DeviceBuffer {
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
 };
 
-constexpr int kNumStageEvents = 7;   // start, vertex, setup, scan, fill, raster, fragment
-constexpr int kCountersPerPass = 4;  // total refs, dropped refs, unprojectable triangles, spare
+constexpr int kNumStageEvents = 8;   // start, clear, vertex, setup, scan, fill, raster, fragment
+constexpr int kCountersPerPass = 8;  // total refs, dropped refs, unprojectable triangles, binned triangles, micro-triangles, spare
 
 }  // namespace
 
@@ -100,7 +100,7 @@ struct sr_target_t {
     uint32_t passes = 0;
     uint32_t* h_counters = nullptr; size_t h_counters_cap = 0;   // pinned, [passes][4], written by the last draw
     uint64_t capacity_at_draw = 0;
-    uint64_t total_refs = 0, unprojectable = 0, binned = 0;
+    uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0;
 };
 
 namespace {
@@ -200,6 +200,10 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     sg.in_flight = true;
     SR_HIP(hipMemsetAsync(dev->counters.ptr, 0, (size_t)passes * kCountersPerPass * 4, st));
 
+    ScreenPlanes sp{};
+    sp.xy = (int2*)dev->screen.ptr;
+    sp.zw = (float2*)((char*)dev->screen.ptr + (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(int2));
+    sp.n_verts = m->n_verts;
     BinBuffers b{};
     b.count_small = (uint32_t*)dev->tile_count.ptr;
     b.count_large = b.count_small + (size_t)vpp * n_tiles;
@@ -229,23 +233,25 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         b.counters = (uint32_t*)dev->counters.ptr + (size_t)pass * kCountersPerPass;
         hipEvent_t* ev = dev->profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
         if (ev) SR_HIP(hipEventRecord(ev[0], st));
-        launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, (ScreenVertex*)dev->screen.ptr, nullptr);
+        launch_clear_vis(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples);
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
-        SR_HIP(hipMemsetAsync(b.count_small, 0, count_words * 4, st));
-        launch_setup(st, m->d_idx, m->n_tris, (const ScreenVertex*)dev->screen.ptr, m->n_verts, g, b, nv);
+        launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        launch_scan(st, b, nv * n_tiles, nv);
+        SR_HIP(hipMemsetAsync(b.count_small, 0, count_words * 4, st));
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0);
         if (ev) SR_HIP(hipEventRecord(ev[3], st));
-        launch_fill(st, g, b, m->n_tris, nv);
+        launch_scan(st, b, nv * n_tiles, nv);
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
-        launch_raster(st, m->d_idx, (const ScreenVertex*)dev->screen.ptr, m->n_verts, g, b, tg->d_vis, v0, nv);
+        launch_fill(st, g, b, m->n_tris, nv);
         if (ev) SR_HIP(hipEventRecord(ev[5], st));
+        launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv);
+        if (ev) SR_HIP(hipEventRecord(ev[6], st));
         FragLaunch f{};
-        f.idx = m->d_idx; f.verts_aos = m->d_aos; f.screen = (const ScreenVertex*)dev->screen.ptr; f.n_verts = m->n_verts; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
+        f.idx = m->d_idx; f.verts_aos = m->d_aos; f.screen = sp; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv;
         launch_fragment(st, f);
-        if (ev) SR_HIP(hipEventRecord(ev[6], st));
+        if (ev) SR_HIP(hipEventRecord(ev[7], st));
     }
     SR_HIP(hipGetLastError());
     SR_HIP(hipMemcpyAsync(tg->h_counters, dev->counters.ptr, (size_t)passes * kCountersPerPass * 4, hipMemcpyDeviceToHost, st));
@@ -261,12 +267,12 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(hipStreamSynchronize(dev->stream));
     if (!tg->check_pending) return SR_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        uint64_t worst = 0, total = 0, unproj = 0, binned = 0;
+        uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0;
         for (uint32_t p = 0; p < tg->passes; ++p) {
             const uint32_t* c = tg->h_counters + (size_t)p * kCountersPerPass;
-            worst = std::max<uint64_t>(worst, c[0]); total += c[0]; unproj += c[2]; binned += c[3];
+            worst = std::max<uint64_t>(worst, c[0]); total += c[0]; unproj += c[2]; binned += c[3]; micro += c[4];
         }
-        tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned;
+        tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned; tg->micro = micro;
         if (worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
         if (attempt == 1) break;
         dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull);
@@ -595,6 +601,7 @@ int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)
     out->shaded_pixels = h[0];
     out->visible_triangles = h[1];
     out->triangles_binned = target->binned;
+    out->triangles_direct = target->micro;
     return SR_OK;
 }
 
@@ -612,16 +619,16 @@ int sr_profile_get(sr_device dev, sr_stage_times* out)
     if (!dev->events_used) return fail(SR_ERR_INVALID_ARGUMENT, "no profiled draw: call sr_profile_enable before sr_draw");
     SR_HIP(hipSetDevice(dev->ordinal));
     SR_HIP(hipStreamSynchronize(dev->stream));
-    float* f = &out->vertex_ms;
+    float* f = &out->clear_ms;
     for (size_t p = 0; p < dev->events_used / kNumStageEvents; ++p) {
         hipEvent_t* ev = &dev->events[p * kNumStageEvents];
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < 7; ++k) {
             float ms = 0.0f;
             SR_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             f[k] += ms;
         }
         float ms = 0.0f;
-        SR_HIP(hipEventElapsedTime(&ms, ev[0], ev[6]));
+        SR_HIP(hipEventElapsedTime(&ms, ev[0], ev[7]));
         out->total_ms += ms;
     }
     return SR_OK;
@@ -639,18 +646,21 @@ int sr_debug_vertex_stage(sr_device dev, sr_mesh mesh, const void* ubo_block, in
     std::memcpy(x.model, u, 64);
     mat4_mul_mat4_host(u + 32, u + 16, x.pv);
     std::memcpy(x.cam, u + 48, 12);
-    void *d_view = nullptr, *d_screen = nullptr, *d_clip = nullptr;
+    void *d_view = nullptr, *d_screen = nullptr, *d_clip = nullptr, *d_planes = nullptr;
     hipError_t e = hipMalloc(&d_view, sizeof x);
     if (e == hipSuccess) e = hipMalloc(&d_screen, (size_t)n * 16);
+    if (e == hipSuccess) e = hipMalloc(&d_planes, (size_t)n * 16);
     if (e == hipSuccess) e = hipMalloc(&d_clip, (size_t)n * 16);
     if (e == hipSuccess) e = hipMemcpy(d_view, &x, sizeof x, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        launch_vertex(dev->stream, mesh->px, mesh->py, mesh->pz, n, (const ViewXform*)d_view, 1, width, height, (ScreenVertex*)d_screen, (float*)d_clip);
+        ScreenPlanes sp{};
+        sp.xy = (int2*)d_planes; sp.zw = (float2*)((char*)d_planes + (size_t)n * 8); sp.n_verts = n;
+        launch_vertex(dev->stream, mesh->px, mesh->py, mesh->pz, n, (const ViewXform*)d_view, 1, width, height, sp, (ScreenVertex*)d_screen, (float*)d_clip);
         e = hipStreamSynchronize(dev->stream);
     }
     if (e == hipSuccess && clip_out) e = hipMemcpy(clip_out, d_clip, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess && screen_out) e = hipMemcpy(screen_out, d_screen, (size_t)n * 16, hipMemcpyDeviceToHost);
-    (void)hipFree(d_view); (void)hipFree(d_screen); (void)hipFree(d_clip);
+    (void)hipFree(d_view); (void)hipFree(d_screen); (void)hipFree(d_clip); (void)hipFree(d_planes);
     SR_HIP(e);
     return SR_OK;
 }

@@ -41,6 +41,22 @@ struct ScreenVertex {    // 16 bytes; rw == 0 marks a vertex that cannot be proj
     float rw;            // 1 / w_clip
 };
 
+// Window-space vertices of a pass are stored as two planes, so that a stage only pulls the half it
+// needs through the caches: triangle set-up reads xy only, the rasteriser xy and z.
+constexpr int32_t kBadVertexX = INT32_MIN;   // xy.x of a vertex that cannot be projected
+struct ScreenPlanes {
+    int2* xy;      // [views][n_verts]: window x, y in 1/256 pixel
+    float2* zw;    // [views][n_verts]: depth, 1/w (0 for an unprojectable vertex)
+    uint32_t n_verts;
+};
+__device__ inline ScreenVertex load_screen_vertex(const ScreenPlanes& sp, size_t i)
+{
+    const int2 a = sp.xy[i];
+    const float2 b = sp.zw[i];
+    ScreenVertex v; v.X = a.x; v.Y = a.y; v.z = b.x; v.rw = b.y;
+    return v;
+}
+
 struct TexDesc {
     const uint32_t* texels;  // RGBA8, all levels back to back
     int w, h, levels;
@@ -197,7 +213,7 @@ struct BinBuffers {
     uint32_t block_stride;    // coprime with n_blocks: hardware block i works on triangle block (i * block_stride) % n_blocks, so that
                               // blocks running at the same time touch different tiles (their per-tile atomics do not pile up)
     uint32_t n_blocks;        // set-up blocks per view
-    uint32_t* counters;       // [4]: total refs, dropped refs, unprojectable triangles, binned triangles
+    uint32_t* counters;       // [8]: total refs, dropped refs, unprojectable triangles, binned triangles, micro-triangles resolved directly
 };
 
 }  // namespace sr

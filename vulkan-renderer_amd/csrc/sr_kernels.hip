@@ -4,6 +4,8 @@
 #include "sr_device.h"
 #include "sr_launch.h"
 
+#include <algorithm>
+
 namespace sr {
 
 // =================================================================================================
@@ -19,12 +21,22 @@ __global__ __launch_bounds__(256) void split_positions_kernel(const float4* __re
 }
 
 // =================================================================================================
+// stage 0: clear the visibility buffer (depth 1.0, no triangle): 16 bytes per lane, grid-stride
+// =================================================================================================
+__global__ __launch_bounds__(256) void clear_vis_kernel(ulonglong2* __restrict__ vis2, size_t n2, unsigned long long* __restrict__ tail)
+{
+    const ulonglong2 c = make_ulonglong2(kVisClear, kVisClear);
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256u) vis2[i] = c;
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0) *tail = kVisClear;
+}
+
+// =================================================================================================
 // stage 1: vertex shader (shaders/shader.vert:20-27) + perspective divide + viewport + snapping
 // one thread per (vertex, view); coalesced 4-byte plane loads, one 16-byte store
 // =================================================================================================
 __global__ __launch_bounds__(256) void vertex_kernel(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                      uint32_t n, const ViewXform* __restrict__ views, int W, int H,
-                                                     ScreenVertex* __restrict__ out, float4* __restrict__ clip_out)
+                                                     ScreenPlanes out, ScreenVertex* __restrict__ debug_out, float4* __restrict__ clip_out)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t view = blockIdx.y;
@@ -32,20 +44,16 @@ __global__ __launch_bounds__(256) void vertex_kernel(const float* __restrict__ p
     const ViewXform& vx = views[view];
     float clip[4];
     const ScreenVertex sv = project_vertex(vx, px[i], py[i], pz[i], W, H, clip);
-    reinterpret_cast<int4*>(out)[(size_t)view * n + i] = make_int4(sv.X, sv.Y, __float_as_int(sv.z), __float_as_int(sv.rw));
-    if (clip_out) clip_out[(size_t)view * n + i] = make_float4(clip[0], clip[1], clip[2], clip[3]);
+    const size_t o = (size_t)view * n + i;
+    out.xy[o] = make_int2(sv.rw == 0.0f ? kBadVertexX : sv.X, sv.Y);
+    out.zw[o] = make_float2(sv.z, sv.rw);
+    if (debug_out) debug_out[o] = sv;
+    if (clip_out) clip_out[o] = make_float4(clip[0], clip[1], clip[2], clip[3]);
 }
 
 // =================================================================================================
 // stage 2a: triangle set-up, culling, tile counting and compaction of the survivors
 // =================================================================================================
-__device__ inline ScreenVertex load_sv(const ScreenVertex* p)
-{
-    const int4 v = *reinterpret_cast<const int4*>(p);
-    ScreenVertex s; s.X = v.x; s.Y = v.y; s.z = __int_as_float(v.z); s.rw = __int_as_float(v.w);
-    return s;
-}
-
 __device__ inline uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Binning.  Same-address global atomics are expensive (they serialise at the memory side), and a
@@ -74,28 +82,107 @@ __device__ inline uint32_t hash_slot(uint32_t* keys, uint32_t tile)
     return kHashSize;
 }
 
-template <int S>
-__global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris,
-                                                    const ScreenVertex* __restrict__ sv_all, uint32_t n_verts,
-                                                    FrameGeom g, BinBuffers b)
+// Micro-triangles (bounding box of at most kMicroPixels pixels, under 64 pixels before clipping to
+// the stored rectangle) never enter a tile list: the set-up kernel tests their few samples itself and
+// resolves the covered ones with a 64-bit atomic min straight into the visibility buffer in HBM.
+// Same integer edge functions, same depth arithmetic as the tile rasteriser, so it makes no
+// difference to the result which path a triangle takes.
+constexpr int kMicroPixels = 8;
+
+struct MicroEdges {
+    int32_t ax, ay, bx, by, cx, cy;   // a = v0, b = v2, c = v1
+    int32_t bias_a, bias_b, bias_c;
+};
+__device__ inline MicroEdges micro_edges(const int2& v0, const int2& v1, const int2& v2)
 {
-    __shared__ uint32_t s_key[kHashSize];
-    __shared__ uint32_t s_cnt[kHashSize];
+    MicroEdges e;
+    e.ax = v0.x; e.ay = v0.y; e.bx = v2.x; e.by = v2.y; e.cx = v1.x; e.cy = v1.y;
+    e.bias_a = is_top_left(e.cx - e.bx, e.cy - e.by) ? 0 : -1;
+    e.bias_b = is_top_left(e.ax - e.cx, e.ay - e.cy) ? 0 : -1;
+    e.bias_c = is_top_left(e.bx - e.ax, e.by - e.ay) ? 0 : -1;
+    return e;
+}
+__device__ inline void micro_eval(const MicroEdges& e, int32_t px, int32_t py, int32_t& Ea, int32_t& Eb, int32_t& Ec)
+{
+    Ea = (e.cx - e.bx) * (py - e.by) - (e.cy - e.by) * (px - e.bx);
+    Eb = (e.ax - e.cx) * (py - e.cy) - (e.ay - e.cy) * (px - e.cx);
+    Ec = (e.bx - e.ax) * (py - e.ay) - (e.by - e.ay) * (px - e.ax);
+}
+// bit ((j*npx + i)*S + s) set when sample s of pixel (x0+i, y0+j) is covered.  Edge functions are
+// stepped incrementally (exact in integers) from their value at the box's first pixel.
+template <int S>
+__device__ inline uint32_t micro_coverage(const MicroEdges& e, int x0, int y0, int npx, int npy)
+{
+    uint32_t cov = 0;
+    const int32_t sxa = -(e.cy - e.by) * kSubpix, sya = (e.cx - e.bx) * kSubpix;   // change per pixel step in x / y
+    const int32_t sxb = -(e.ay - e.cy) * kSubpix, syb = (e.ax - e.cx) * kSubpix;
+    const int32_t sxc = -(e.by - e.ay) * kSubpix, syc = (e.bx - e.ax) * kSubpix;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int32_t Ra, Rb, Rc;
+        micro_eval(e, x0 * kSubpix + sample_dx(S, s), y0 * kSubpix + sample_dy(S, s), Ra, Rb, Rc);
+        Ra += e.bias_a; Rb += e.bias_b; Rc += e.bias_c;
+        int bit = s;
+        for (int j = 0; j < npy; ++j) {
+            int32_t Ea = Ra, Eb = Rb, Ec = Rc;
+            for (int i = 0; i < npx; ++i) {
+                if ((Ea | Eb | Ec) >= 0) cov |= 1u << bit;
+                Ea += sxa; Eb += sxb; Ec += sxc;
+                bit += S;
+            }
+            Ra += sya; Rb += syb; Rc += syc;
+        }
+    }
+    return cov;
+}
+template <int S>
+__device__ inline void micro_resolve(const MicroEdges& e, uint32_t cov, int x0, int y0, int npx, float z0, float z1, float z2, float rA,
+                                     uint32_t tri, unsigned long long* vis_view, const FrameGeom& g)
+{
+    // walk the box in the same order as micro_coverage; cov is usually one or two bits
+    int i = 0, j = 0;
+    for (uint32_t m = cov; m; ) {
+        uint32_t here = m & ((1u << S) - 1u);
+        m >>= S;
+        for (; here; here &= here - 1u) {
+            const int s = __ffs((int)here) - 1;
+            const int x = x0 + i, y = y0 + j;
+            int32_t Ea, Eb, Ec;
+            micro_eval(e, x * kSubpix + sample_dx(S, s), y * kSubpix + sample_dy(S, s), Ea, Eb, Ec);
+            const float l0 = (float)Ea * rA, l2 = (float)Eb * rA, l1 = (float)Ec * rA;
+            float z = fmaf(l2, z2, fmaf(l1, z1, l0 * z0));
+            z = z + 0.0f;
+            if (z >= 0.0f && z <= 1.0f)
+                atomicMin(&vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S + s], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
+        }
+        if (++i == npx) { i = 0; ++j; }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
+                                                    FrameGeom g, BinBuffers b, unsigned long long* __restrict__ vis, uint32_t view0)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[kHashSize];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHashSize];
     __shared__ uint32_t s_total[2];   // records, live triangles
     const uint32_t view = blockIdx.y;
     const uint32_t tid = threadIdx.x;
     const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * b.block_stride) % b.n_blocks);
     const uint32_t lane = lane_id();
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
     uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
     uint32_t* count_large = b.count_large + (size_t)view * n_tiles;
 #pragma unroll
-    for (uint32_t k = 0; k < kHashSize / 256u; ++k) { s_key[tid + 256u * k] = kHashEmpty; s_cnt[tid + 256u * k] = 0u; }
+    for (uint32_t k = 0; k < kHashSize / 1024u; ++k) {
+        reinterpret_cast<uint4*>(s_key)[tid + 256u * k] = make_uint4(kHashEmpty, kHashEmpty, kHashEmpty, kHashEmpty);
+        reinterpret_cast<uint4*>(s_cnt)[tid + 256u * k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (tid < 2) s_total[tid] = 0u;
-    __syncthreads();
 
     // all index loads first, then all vertex loads: 12 independent gathers in flight per lane
-    const ScreenVertex* sv = sv_all + (size_t)view * n_verts;
+    const int2* xy = sp.xy + (size_t)view * sp.n_verts;
     uint32_t tri[kTrisPerThread], i0[kTrisPerThread], i1[kTrisPerThread], i2[kTrisPerThread];
     bool in_range[kTrisPerThread];
 #pragma unroll
@@ -105,72 +192,134 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
         const uint32_t tt = in_range[k] ? tri[k] : 0u;
         i0[k] = idx[3 * (size_t)tt]; i1[k] = idx[3 * (size_t)tt + 1]; i2[k] = idx[3 * (size_t)tt + 2];
     }
-    int4 r0[kTrisPerThread], r1[kTrisPerThread], r2[kTrisPerThread];
+    int2 r0[kTrisPerThread], r1[kTrisPerThread], r2[kTrisPerThread];
 #pragma unroll
-    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-        r0[k] = *reinterpret_cast<const int4*>(sv + i0[k]);
-        r1[k] = *reinterpret_cast<const int4*>(sv + i1[k]);
-        r2[k] = *reinterpret_cast<const int4*>(sv + i2[k]);
-    }
-    // per triangle: number of records (0 = culled), tile span, and for small triangles the hash slot
-    // and the rank inside the slot's group for each covered tile
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) { r0[k] = xy[i0[k]]; r1[k] = xy[i1[k]]; r2[k] = xy[i2[k]]; }
+    __syncthreads();   // hash table initialised
+
+    // per triangle: tile span (0 records = culled); for small triangles the hash slot and the rank
+    // inside the slot's group of every covered tile
     uint32_t nrec[kTrisPerThread], span[kTrisPerThread];
     uint32_t slot[kTrisPerThread][kMaxSmallTiles], local[kTrisPerThread][kMaxSmallTiles];
-    uint32_t n_unproj = 0, n_live = 0;
+    uint32_t n_unproj = 0, n_live = 0, n_micro = 0, is_large = 0;
+    uint32_t micro_cov[kTrisPerThread], micro_box[kTrisPerThread];   // coverage bits; x0 | y0<<14 | npx<<28
 #pragma unroll
     for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-        nrec[k] = 0; span[k] = 0;
-        const int bad = (r0[k].w == 0) + (r1[k].w == 0) + (r2[k].w == 0);   // 1/w == +0.0f marks an unprojectable vertex
+        nrec[k] = 0; span[k] = 0; micro_cov[k] = 0; micro_box[k] = 0;
+        int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
+        const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
         const int64_t area2 = (int64_t)(r1[k].x - r0[k].x) * (int64_t)(r2[k].y - r0[k].y) - (int64_t)(r2[k].x - r0[k].x) * (int64_t)(r1[k].y - r0[k].y);
         if (in_range[k] && bad > 0 && bad < 3) ++n_unproj;
+        bool live = false;
         if (in_range[k] && bad == 0 && area2 < 0) {
             int x0, x1, y0, y1;
             pixel_span<S>(min(r0[k].x, min(r1[k].x, r2[k].x)), max(r0[k].x, max(r1[k].x, r2[k].x)), x0, x1);
             pixel_span<S>(min(r0[k].y, min(r1[k].y, r2[k].y)), max(r0[k].y, max(r1[k].y, r2[k].y)), y0, y1);
             x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
             y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
-            if (x0 <= x1 && y0 <= y1) {
+            const int npx = x1 - x0 + 1, npy = y1 - y0 + 1;
+            const int bw = max(r0[k].x, max(r1[k].x, r2[k].x)) - min(r0[k].x, min(r1[k].x, r2[k].x));
+            const int bh = max(r0[k].y, max(r1[k].y, r2[k].y)) - min(r0[k].y, min(r1[k].y, r2[k].y));
+            if (npx > 0 && npy > 0 && npx * npy <= kMicroPixels && bw < 16384 && bh < 16384) {
+                // micro-triangle: resolved below without binning (or dropped if it covers no sample)
+                micro_cov[k] = micro_coverage<S>(micro_edges(r0[k], r1[k], r2[k]), x0, y0, npx, npy);
+                micro_box[k] = (uint32_t)x0 | ((uint32_t)y0 << 14) | ((uint32_t)npx << 28);
+                if (micro_cov[k]) ++n_micro;
+            } else if (x0 <= x1 && y0 <= y1) {
+                live = true;
                 ++n_live;
-                const int tx0 = (x0 - g.rx) >> g.tile_log2, tx1 = (x1 - g.rx) >> g.tile_log2;
-                const int ty0 = (y0 - g.ry) >> g.tile_log2, ty1 = (y1 - g.ry) >> g.tile_log2;
+                tx0 = (x0 - g.rx) >> g.tile_log2; ty0 = (y0 - g.ry) >> g.tile_log2;
+                const int tx1 = (x1 - g.rx) >> g.tile_log2, ty1 = (y1 - g.ry) >> g.tile_log2;
                 span[k] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
-                const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
-                bool small = nx <= 2 && ny <= 2;
-                if (small) {
-                    nrec[k] = (uint32_t)(nx * ny);
-#pragma unroll
-                    for (uint32_t j = 0; j < kMaxSmallTiles; ++j) {
-                        slot[k][j] = kHashSize;
-                        if (j < nrec[k]) {
-                            const int tx = tx0 + (int)(j % (uint32_t)nx), ty = ty0 + (int)(j / (uint32_t)nx);
-                            slot[k][j] = hash_slot(s_key, (uint32_t)(ty * g.tiles_x + tx));
-                            if (slot[k][j] == kHashSize) small = false;
-                        }
-                    }
+                nx = tx1 - tx0 + 1; ny = ty1 - ty0 + 1;
+            }
+        }
+        bool small = live && nx <= 2 && ny <= 2;
+        // first covered tile of every small triangle: lanes of the wave that share a tile are
+        // counted with ballots, one lane per distinct tile touches the block's table
+        {
+            const uint32_t tile0 = (uint32_t)(ty0 * g.tiles_x + tx0);
+            slot[k][0] = kHashSize; local[k][0] = 0;
+            bool pend = small;
+            uint64_t m = __ballot(pend);
+            while (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t lt = (uint32_t)__shfl((int)tile0, leader);
+                const uint64_t same = __ballot(pend && tile0 == lt);
+                uint32_t sl = kHashSize, base = 0;
+                if (lane == (uint32_t)leader) {
+                    sl = hash_slot(s_key, lt);
+                    if (sl < kHashSize) base = atomicAdd(&s_cnt[sl], (uint32_t)__popcll(same));
                 }
-                if (small) {
+                sl = (uint32_t)__shfl((int)sl, leader); base = (uint32_t)__shfl((int)base, leader);
+                if (pend && tile0 == lt) {
+                    slot[k][0] = sl; local[k][0] = base + (uint32_t)__popcll(same & lanes_below);
+                    if (sl == kHashSize) small = false;   // table too crowded: handle as a large triangle
+                    pend = false;
+                }
+                m &= ~same;
+            }
+        }
+        if (small) {
+            nrec[k] = (uint32_t)(nx * ny);
 #pragma unroll
-                    for (uint32_t j = 0; j < kMaxSmallTiles; ++j)
-                        if (j < nrec[k]) local[k][j] = atomicAdd(&s_cnt[slot[k][j]], 1u);
-                } else {
-                    nrec[k] = 1;
-                    slot[k][0] = kHashSize;   // marks the large-triangle record
-                    for (int ty = ty0; ty <= ty1; ++ty)
-                        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&count_large[ty * g.tiles_x + tx], 1u);
+            for (uint32_t j = 1; j < kMaxSmallTiles; ++j) {   // further tiles of triangles that straddle a tile border (few)
+                slot[k][j] = kHashSize; local[k][j] = 0;
+                if (j < nrec[k]) {
+                    const uint32_t tile = (uint32_t)((ty0 + (int)(j / (uint32_t)nx)) * g.tiles_x + tx0 + (int)(j % (uint32_t)nx));
+                    slot[k][j] = hash_slot(s_key, tile);
+                    if (slot[k][j] < kHashSize) local[k][j] = atomicAdd(&s_cnt[slot[k][j]], 1u);
+                    else atomicAdd(&count_large[tile], 1u);   // crowded table: this (triangle, tile) pair takes the slow path
                 }
             }
+        } else if (live) {
+            // large triangle, or a small one whose first tile found no room in the table: one record
+            // with the whole tile span, appended by the fill pass
+            nrec[k] = 1;
+            is_large |= 1u << k;
+            const int tx1 = (int)((span[k] >> 16) & 255u), ty1 = (int)(span[k] >> 24);
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&count_large[ty * g.tiles_x + tx], 1u);
+        }
+    }
+    // micro-triangles with a covered sample: fetch the three depths (all loads first), then resolve
+    {
+        const float2* zw = sp.zw + (size_t)view * sp.n_verts;
+        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
+        float z0[kTrisPerThread], z1[kTrisPerThread], z2[kTrisPerThread];
+#pragma unroll
+        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+            z0[k] = z1[k] = z2[k] = 0.0f;
+            if (micro_cov[k]) { z0[k] = zw[i0[k]].x; z1[k] = zw[i1[k]].x; z2[k] = zw[i2[k]].x; }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+            if (!micro_cov[k]) continue;
+            const int32_t A = -((r1[k].x - r0[k].x) * (r2[k].y - r0[k].y) - (r2[k].x - r0[k].x) * (r1[k].y - r0[k].y));
+            micro_resolve<S>(micro_edges(r0[k], r1[k], r2[k]), micro_cov[k], (int)(micro_box[k] & 16383u), (int)((micro_box[k] >> 14) & 16383u),
+                             (int)(micro_box[k] >> 28), z0[k], z1[k], z2[k], 1.0f / (float)A, tri[k], vis_view, g);
         }
     }
     if (n_unproj) atomicAdd(&b.counters[2], n_unproj);   // triangles that would need clipping (rare)
-    // place of this lane's records inside the block's segment (any order will do)
+    // place of this lane's records inside the block's segment (any order will do): wave prefix sum
     uint32_t first[kTrisPerThread];
-#pragma unroll
-    for (uint32_t k = 0; k < kTrisPerThread; ++k) first[k] = nrec[k] ? atomicAdd(&s_total[0], nrec[k]) : 0u;
     {
-        const uint64_t any = __ballot(n_live != 0);
-        uint32_t w = n_live;
-        for (int o = 32; o > 0; o >>= 1) w += (uint32_t)__shfl_down((int)w, o);
-        if (any && lane == 0) atomicAdd(&s_total[1], w);
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kTrisPerThread; ++k) mine += nrec[k];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+        uint32_t live_sum = n_live | (n_micro << 16);   // two 16-bit counts per lane, summed together (a block has 1024 triangles)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) live_sum += (uint32_t)__shfl_down((int)live_sum, o);
+        uint32_t wave_base = 0;
+        if (lane == 63u) wave_base = atomicAdd(&s_total[0], incl);
+        if (lane == 0u && live_sum) atomicAdd(&s_total[1], live_sum);
+        wave_base = (uint32_t)__shfl((int)wave_base, 63);
+        uint32_t run = wave_base + incl - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < kTrisPerThread; ++k) { first[k] = run; run += nrec[k]; }
     }
     __syncthreads();
     // one returning global atomic per distinct tile of the block reserves the group's place in the
@@ -185,14 +334,17 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
 #pragma unroll
     for (uint32_t k = 0; k < kTrisPerThread; ++k) {
         if (nrec[k] == 0) continue;
-        if (slot[k][0] == kHashSize) {
+        if (is_large & (1u << k)) {
             BinRecord rec; rec.tri = tri[k]; rec.where = span[k]; rec.rel = kLargeTri;
             seg[first[k]] = rec;
         } else {
+            const uint32_t tx0 = span[k] & 255u, ty0 = (span[k] >> 8) & 255u, nx = ((span[k] >> 16) & 255u) - tx0 + 1u;
 #pragma unroll
             for (uint32_t j = 0; j < kMaxSmallTiles; ++j)
                 if (j < nrec[k]) {
-                    BinRecord rec; rec.tri = tri[k]; rec.where = s_key[slot[k][j]]; rec.rel = s_cnt[slot[k][j]] + local[k][j];
+                    BinRecord rec; rec.tri = tri[k];
+                    if (slot[k][j] < kHashSize) { rec.where = s_key[slot[k][j]]; rec.rel = s_cnt[slot[k][j]] + local[k][j]; }
+                    else { const uint32_t tx = tx0 + j % nx, ty = ty0 + j / nx; rec.where = tx | (ty << 8) | (tx << 16) | (ty << 24); rec.rel = kLargeTri; }
                     seg[first[k] + j] = rec;
                 }
         }
@@ -228,10 +380,11 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
     for (uint32_t i = beg; i < end; ++i) { offset[i] = run; run += count_a[i] + count_b[i]; }
     if (tid == 1023u) { offset[n] = part[1023]; counters[0] = part[1023]; }
     // number of binned triangles (instrumentation)
-    uint32_t surv = 0;
-    for (uint32_t i = tid; i < n_block_counts; i += 1024u) surv += block_live[i];
-    for (int o = 32; o > 0; o >>= 1) surv += (uint32_t)__shfl_down((int)surv, o);
+    uint32_t surv = 0, micro = 0;
+    for (uint32_t i = tid; i < n_block_counts; i += 1024u) { const uint32_t v = block_live[i]; surv += v & 0xFFFFu; micro += v >> 16; }
+    for (int o = 32; o > 0; o >>= 1) { surv += (uint32_t)__shfl_down((int)surv, o); micro += (uint32_t)__shfl_down((int)micro, o); }
     if ((tid & 63u) == 0u && surv) atomicAdd(&counters[3], surv);
+    if ((tid & 63u) == 0u && micro) atomicAdd(&counters[4], micro);
 }
 
 // =================================================================================================
@@ -316,7 +469,7 @@ __device__ inline void raster_pixel32(const TriSetup& ts, uint32_t tri, int x, i
 }
 
 template <int TL2, int S, int TPB>
-__global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict__ idx, const ScreenVertex* __restrict__ sv_all, uint32_t n_verts,
+__global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                      FrameGeom g, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ refs,
                                                      uint32_t ref_capacity, unsigned long long* __restrict__ vis, uint32_t view0)
 {
@@ -330,23 +483,59 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
     const int px1 = min(px0 + T, g.rx + g.rw) - 1, py1 = min(py0 + T, g.ry + g.rh) - 1;
     const uint32_t tid = threadIdx.x, lane = lane_id();
 
-    for (int i = tid; i < T * T * S; i += TPB) tile[i] = kVisClear;
-    __syncthreads();
-
     const uint32_t beg = tile_offset[(size_t)view * n_tiles + tile_id];
     uint32_t end = tile_offset[(size_t)view * n_tiles + tile_id + 1];
     end = min(end, ref_capacity);
-    const ScreenVertex* sv = sv_all + (size_t)view * n_verts;
+    if (beg >= end) return;   // nothing binned here: the visibility buffer was cleared before set-up (uniform over the block)
+
+    for (int i = tid; i < T * T * S; i += TPB) tile[i] = kVisClear;
+    __syncthreads();
+    const int2* xy = sp.xy + (size_t)view * sp.n_verts;
+    const float2* zw = sp.zw + (size_t)view * sp.n_verts;
+
+    // Software pipeline over the tile's list: reference -> indices -> vertices are three dependent
+    // loads, so while one triangle is rasterised the vertices of the next one, the indices of the one
+    // after and the reference of the third are already in flight.
+    struct Fetched { int2 a0, a1, a2; float z0, z1, z2; };
+    auto load_ref = [&](uint32_t r) -> uint32_t {
+        uint32_t t = kNoTri;
+        if (r < end) { t = refs[r]; if (t >= n_tris) t = kNoTri; }   // (lists only ever hold valid ids; cheap insurance against a fault)
+        return t;
+    };
+    auto load_idx = [&](uint32_t t, uint32_t& i0, uint32_t& i1, uint32_t& i2) {
+        i0 = i1 = i2 = 0;
+        if (t != kNoTri) { i0 = idx[3 * (size_t)t]; i1 = idx[3 * (size_t)t + 1]; i2 = idx[3 * (size_t)t + 2]; }
+    };
+    auto load_verts = [&](uint32_t t, uint32_t i0, uint32_t i1, uint32_t i2) -> Fetched {
+        Fetched f{};
+        if (t != kNoTri) {
+            f.a0 = xy[i0]; f.a1 = xy[i1]; f.a2 = xy[i2];
+            f.z0 = zw[i0].x; f.z1 = zw[i1].x; f.z2 = zw[i2].x;
+        }
+        return f;
+    };
+    uint32_t tri_cur = load_ref(beg + tid), tri_n1 = load_ref(beg + TPB + tid), tri_n2 = load_ref(beg + 2 * TPB + tid);
+    uint32_t c0, c1, c2, n0, n1, n2;
+    load_idx(tri_cur, c0, c1, c2);
+    load_idx(tri_n1, n0, n1, n2);
+    Fetched f_cur = load_verts(tri_cur, c0, c1, c2);
 
     for (uint32_t base = beg; base < end; base += TPB) {
-        const uint32_t r = base + tid;
-        bool have = r < end;
+        // next stages first, so that their latency overlaps this iteration's work
+        const Fetched f_n1 = load_verts(tri_n1, n0, n1, n2);
+        uint32_t m0, m1, m2;
+        load_idx(tri_n2, m0, m1, m2);
+        const uint32_t tri_n3 = load_ref(base + 3 * TPB + tid);
+
+        bool have = tri_cur != kNoTri;
         LaneTri L;
+        L.tri = tri_cur;
         int npix = 0;
         if (have) {
-            L.tri = refs[r];
-            const uint32_t i0 = idx[3 * (size_t)L.tri], i1 = idx[3 * (size_t)L.tri + 1], i2 = idx[3 * (size_t)L.tri + 2];
-            const ScreenVertex v0 = load_sv(sv + i0), v1 = load_sv(sv + i1), v2 = load_sv(sv + i2);
+            ScreenVertex v0, v1, v2;
+            v0.X = f_cur.a0.x; v0.Y = f_cur.a0.y; v0.z = f_cur.z0; v0.rw = f_cur.a0.x == kBadVertexX ? 0.0f : 1.0f;
+            v1.X = f_cur.a1.x; v1.Y = f_cur.a1.y; v1.z = f_cur.z1; v1.rw = f_cur.a1.x == kBadVertexX ? 0.0f : 1.0f;
+            v2.X = f_cur.a2.x; v2.Y = f_cur.a2.y; v2.z = f_cur.z2; v2.rw = f_cur.a2.x == kBadVertexX ? 0.0f : 1.0f;
             have = setup_triangle(v0, v1, v2, L.ts) == 1;
             if (have) {
                 pixel_span<S>(L.ts.minX, L.ts.maxX, L.x0, L.x1);
@@ -357,6 +546,9 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
                 if (have) npix = (L.x1 - L.x0 + 1) * (L.y1 - L.y0 + 1);
             }
         }
+        tri_cur = tri_n1; f_cur = f_n1;
+        tri_n1 = tri_n2; n0 = m0; n1 = m1; n2 = m2;
+        tri_n2 = tri_n3;
         if (have && npix <= kSmall) {
             if (fits_32bit(L.ts)) {
                 for (int y = L.y0; y <= L.y1; ++y)
@@ -399,7 +591,8 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
     unsigned long long* out = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
     for (int i = tid; i < T * T * S; i += TPB) {
         const int s = i % S, p = i / S, lx = p & (T - 1), ly = p >> TL2;
-        if (lx < tw && ly < th) out[((size_t)(py0 - g.ry + ly) * g.rw + (px0 - g.rx + lx)) * S + s] = tile[i];
+        // merge with what micro-triangles already resolved in HBM; untouched samples cost nothing
+        if (lx < tw && ly < th && tile[i] != kVisClear) atomicMin(&out[((size_t)(py0 - g.ry + ly) * g.rw + (px0 - g.rx + lx)) * S + s], tile[i]);
     }
 }
 
@@ -574,8 +767,7 @@ __device__ inline void fragment_main(const float* wp, const float* N, const floa
 struct FragParams {
     const uint32_t* idx;
     const float4* verts;       // 2 float4 per vertex: (pos.xyz, n.x) (n.yz, uv)
-    const ScreenVertex* screen; // window-space vertices of the views of this pass, [views][n_verts]
-    uint32_t n_verts;
+    ScreenPlanes screen;       // window-space vertices of the views of this pass
     const ViewXform* views;    // views of this pass
     const unsigned long long* vis;
     uint32_t* color;
@@ -588,14 +780,14 @@ struct FragParams {
 // shades triangle `tri` at pixel (x,y): packed B,G,R,A.  Barycentrics are evaluated in float relative
 // to vertex 0 (exact for triangles up to a few hundred pixels, 2^-24 relative otherwise); the values
 // at the other pixels of the 2x2 quad follow from their screen-space gradients.
-__device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, const ScreenVertex* sv, uint32_t tri, int x, int y,
+__device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, size_t sv_base, uint32_t tri, int x, int y,
                                        const float* dec, const float* thr)
 {
     const uint32_t i0 = p.idx[3 * (size_t)tri], i1 = p.idx[3 * (size_t)tri + 1], i2 = p.idx[3 * (size_t)tri + 2];
     const float4 a0 = p.verts[2 * (size_t)i0], b0 = p.verts[2 * (size_t)i0 + 1];
     const float4 a1 = p.verts[2 * (size_t)i1], b1 = p.verts[2 * (size_t)i1 + 1];
     const float4 a2 = p.verts[2 * (size_t)i2], b2 = p.verts[2 * (size_t)i2 + 1];
-    const ScreenVertex v0 = load_sv(sv + i0), v1 = load_sv(sv + i1), v2 = load_sv(sv + i2);
+    const ScreenVertex v0 = load_screen_vertex(p.screen, sv_base + i0), v1 = load_screen_vertex(p.screen, sv_base + i1), v2 = load_screen_vertex(p.screen, sv_base + i2);
     // edge vectors relative to v0, 1/256 pixel; weights: l1 = cross(p - v0, e2) / A', l2 = cross(e1, p - v0) / A'
     const float e1x = (float)(v1.X - v0.X), e1y = (float)(v1.Y - v0.Y);
     const float e2x = (float)(v2.X - v0.X), e2y = (float)(v2.Y - v0.Y);
@@ -662,7 +854,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
     const unsigned long long* v = p.vis + pix * S;
     const int x = p.g.rx + lx, y = p.g.ry + ly;
     const ViewXform& vx = p.views[view];
-    const ScreenVertex* sv = p.screen + (size_t)view * p.n_verts;
+    const size_t sv = (size_t)view * p.screen.n_verts;
     uint32_t ids[S], col[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) ids[s] = (uint32_t)v[s];
@@ -778,20 +970,28 @@ void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* 
     split_positions_kernel<<<div_up(n, 256), 256, 0, st>>>((const float4*)aos, n, px, py, pz);
 }
 
-void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
-                   int W, int H, ScreenVertex* out, float* clip_out)
+void launch_clear_vis(hipStream_t st, uint64_t* vis, size_t n)
 {
-    if (!n || !n_views) return;
-    vertex_kernel<<<dim3(div_up(n, 256), n_views), 256, 0, st>>>(px, py, pz, n, views, W, H, out, (float4*)clip_out);
+    if (!n) return;
+    const size_t n2 = n / 2;
+    const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>((n2 + 255) / 256, 1), 256 * 16);
+    clear_vis_kernel<<<blocks, 256, 0, st>>>((ulonglong2*)vis, n2, (n & 1) ? (unsigned long long*)vis + (n - 1) : nullptr);
 }
 
-void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g,
-                  const BinBuffers& b, uint32_t n_views)
+void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
+                   int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out)
+{
+    if (!n || !n_views) return;
+    vertex_kernel<<<dim3(div_up(n, 256), n_views), 256, 0, st>>>(px, py, pz, n, views, W, H, out, debug_out, (float4*)clip_out);
+}
+
+void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
+                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0)
 {
     if (!n_tris || !n_views) return;
     const dim3 grid(b.n_blocks, n_views);
-    if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sv, n_verts, g, b);
-    else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sv, n_verts, g, b);
+    if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
+    else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
 }
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views)
@@ -805,20 +1005,20 @@ void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32
     fill_kernel<<<dim3(b.n_blocks, n_views), 256, 0, st>>>(g, b);
 }
 
-void launch_raster(hipStream_t st, const uint32_t* idx, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g, const BinBuffers& b,
+void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
                    uint64_t* vis, uint32_t view0, uint32_t n_views)
 {
     if (!n_views) return;
     const dim3 grid((uint32_t)(g.tiles_x * g.tiles_y), n_views);
     unsigned long long* v = (unsigned long long*)vis;
     if (g.samples == 1 && g.tile_log2 == 6)
-        raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+        raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
     else if (g.samples == 1 && g.tile_log2 == 5)
-        raster_kernel<5, 1, 256><<<grid, 256, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+        raster_kernel<5, 1, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
     else if (g.samples == 4 && g.tile_log2 == 5)
-        raster_kernel<5, 4, 1024><<<grid, 1024, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+        raster_kernel<5, 4, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
     else if (g.samples == 4 && g.tile_log2 == 4)
-        raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, sv, n_verts, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+        raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
 }
 
 uint32_t setup_block_triangles() { return kBlockTris; }
@@ -833,7 +1033,7 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
 {
     if (!f.n_views) return;
     FragParams p;
-    p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.screen = f.screen; p.n_verts = f.n_verts; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
+    p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.screen = f.screen; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
     p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness;
     p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0;
     const dim3 grid(div_up((uint32_t)f.g.rw, 32), div_up((uint32_t)f.g.rh, 8), f.n_views), block(32, 8);

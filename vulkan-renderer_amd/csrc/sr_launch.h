@@ -8,8 +8,7 @@ namespace sr {
 struct FragLaunch {
     const uint32_t* idx;
     const void* verts_aos;     // the reference's 32-byte vertex records
-    const ScreenVertex* screen; // window-space vertices of this pass, [views][n_verts]
-    uint32_t n_verts;
+    ScreenPlanes screen;       // window-space vertices of this pass
     const ViewXform* views;
     const uint64_t* vis;
     uint32_t* color;
@@ -22,12 +21,13 @@ struct FragLaunch {
 
 void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz);
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
-                   int W, int H, ScreenVertex* out, float* clip_out);
-void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g,
-                  const BinBuffers& b, uint32_t n_views);
+                   int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out);
+void launch_clear_vis(hipStream_t st, uint64_t* vis, size_t n_words);
+void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
+                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0);
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views);
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views);
-void launch_raster(hipStream_t st, const uint32_t* idx, const ScreenVertex* sv, uint32_t n_verts, const FrameGeom& g, const BinBuffers& b,
+void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
                    uint64_t* vis, uint32_t view0, uint32_t n_views);
 bool raster_config_supported(int samples, int tile_log2);
 uint32_t setup_block_triangles();   // triangles handled by one set-up block

@@ -48,14 +48,14 @@ class Rect(C.Structure):
 
 class DrawStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("vertices", "triangles", "triangles_binned", "tile_refs", "triangles_unprojectable",
-                                           "shaded_pixels", "visible_triangles", "pixels")]
+                                           "shaded_pixels", "visible_triangles", "pixels", "triangles_direct")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
 class StageTimes(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("vertex_ms", "setup_ms", "scan_ms", "fill_ms", "raster_ms", "fragment_ms", "total_ms")]
+    _fields_ = [(n, C.c_float) for n in ("clear_ms", "vertex_ms", "setup_ms", "scan_ms", "fill_ms", "raster_ms", "fragment_ms", "total_ms")]
 
     def as_dict(self):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
