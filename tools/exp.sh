@@ -13,4 +13,4 @@ PY
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | grep -E "error" ; (timeout 1500 /usr/local/graft/bin/gpurun --timeout 600 -- "timeout -k 10 300 python -u bench.py --steps 20 --no-cpu-baseline > gpurun_out/bench_a.log 2>&1; echo exit=\$?; tail -2 gpurun_out/bench_a.log") 2>&1 | grep "^{" | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_ms'])"
-cp /tmp/sr_kernels.exp.bak vulkan-renderer_amd/csrc/sr_kernels.hip
+cp /tmp/sr_kernels.exp.bak vulkan-renderer_amd/csrc/sr_kernels.hip; python -c "import __graft_entry__ as g; g.build()"

@@ -60,7 +60,7 @@ struct sr_device_t {
     DeviceBuffer screen, tile_count, tile_offset, survivors, survivor_count, refs, views, counters;
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
-    struct Staging { ViewXform* h = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool in_flight = false; };
+    struct Staging { ViewXform* h = nullptr; void* d = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool in_flight = false; };   // h: pinned + mapped, d: its device address
     Staging staging[4];
     unsigned staging_next = 0;
     uint64_t ref_capacity = 0;
@@ -98,7 +98,7 @@ struct sr_target_t {
     sr_texture tex[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<ViewXform> views;
     uint32_t passes = 0;
-    uint32_t* h_counters = nullptr; size_t h_counters_cap = 0;   // pinned, [passes][4], written by the last draw
+    uint32_t* h_counters = nullptr; void* hd_counters = nullptr; size_t h_counters_cap = 0;   // pinned + mapped, [passes][8], written by the scan kernel of the last draw
     uint64_t capacity_at_draw = 0;
     uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0;
 };
@@ -132,7 +132,7 @@ int choose_tile_log2(const sr_device_t* dev, int samples)
 // per-view scratch bytes of a pass
 size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g)
 {
-    return (size_t)m->n_verts * sizeof(ScreenVertex) + ((size_t)m->n_tris + 1024) * 4 * sizeof(BinRecord) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 16 + 64;
+    return (size_t)m->n_verts * sizeof(ScreenVertex) + ((size_t)m->n_tris + 1024) * (4 * sizeof(BinRecord) + 4) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 16 + 64;
 }
 
 uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views)
@@ -164,26 +164,31 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     const uint32_t n_blocks = (m->n_tris + bt - 1u) / bt;
     const size_t count_words = (size_t)vpp * n_tiles * 3;
     SR_HIP(dev->screen.ensure((size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex)));
-    SR_HIP(dev->tile_count.ensure((count_words + 2 * (size_t)vpp * std::max(n_blocks, 1u)) * 4));
+    // layout of the binning state: [count_small | count_large | cursor_large | counters of this pass] (zeroed at the
+    // start of every pass, padded to 16 bytes) [block_count | block_live | pending_count]
+    const size_t zero_words = (count_words + kCountersPerPass + 3) & ~(size_t)3;
+    SR_HIP(dev->tile_count.ensure((zero_words + 3 * (size_t)vpp * std::max(n_blocks, 1u)) * 4));
+    SR_HIP(dev->survivor_count.ensure((size_t)vpp * std::max(n_blocks, 1u) * bt * 4));
     SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
     SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * setup_block_records() * sizeof(BinRecord)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
     SR_HIP(dev->views.ensure((size_t)n_views * sizeof(ViewXform)));
-    SR_HIP(dev->counters.ensure((size_t)passes * kCountersPerPass * 4));
     sr_device_t::Staging& sg = dev->staging[dev->staging_next++ & 3u];
     if (!sg.ev) SR_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
     if (sg.in_flight) { SR_HIP(hipEventSynchronize(sg.ev)); sg.in_flight = false; }
     if (sg.cap < n_views) {
         if (sg.h) SR_HIP(hipHostFree(sg.h));
         sg.h = nullptr; sg.cap = 0;
-        SR_HIP(hipHostMalloc((void**)&sg.h, (size_t)n_views * sizeof(ViewXform), hipHostMallocDefault));
+        SR_HIP(hipHostMalloc((void**)&sg.h, (size_t)n_views * sizeof(ViewXform), hipHostMallocMapped));
+        SR_HIP(hipHostGetDevicePointer(&sg.d, sg.h, 0));
         sg.cap = n_views;
     }
     if (tg->h_counters_cap < passes) {
         SR_HIP(hipStreamSynchronize(st));
         if (tg->h_counters) SR_HIP(hipHostFree(tg->h_counters));
         tg->h_counters = nullptr; tg->h_counters_cap = 0;
-        SR_HIP(hipHostMalloc((void**)&tg->h_counters, (size_t)passes * kCountersPerPass * 4, hipHostMallocDefault));
+        SR_HIP(hipHostMalloc((void**)&tg->h_counters, (size_t)passes * kCountersPerPass * 4, hipHostMallocMapped));
+        SR_HIP(hipHostGetDevicePointer(&tg->hd_counters, tg->h_counters, 0));
         tg->h_counters_cap = passes;
     }
     if (dev->profiling) {
@@ -195,10 +200,6 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     } else dev->events_used = 0;
 
     std::memcpy(sg.h, tg->views.data(), (size_t)n_views * sizeof(ViewXform));
-    SR_HIP(hipMemcpyAsync(dev->views.ptr, sg.h, (size_t)n_views * sizeof(ViewXform), hipMemcpyHostToDevice, st));
-    SR_HIP(hipEventRecord(sg.ev, st));
-    sg.in_flight = true;
-    SR_HIP(hipMemsetAsync(dev->counters.ptr, 0, (size_t)passes * kCountersPerPass * 4, st));
 
     ScreenPlanes sp{};
     sp.xy = (int2*)dev->screen.ptr;
@@ -208,8 +209,11 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     b.count_small = (uint32_t*)dev->tile_count.ptr;
     b.count_large = b.count_small + (size_t)vpp * n_tiles;
     b.cursor_large = b.count_large + (size_t)vpp * n_tiles;
-    b.block_count = b.count_small + count_words;
+    b.counters = b.count_small + count_words;
+    b.block_count = b.count_small + zero_words;
     b.block_live = b.block_count + (size_t)vpp * std::max(n_blocks, 1u);
+    b.pending_count = b.block_live + (size_t)vpp * std::max(n_blocks, 1u);
+    b.pending = (uint32_t*)dev->survivor_count.ptr;
     b.n_blocks = n_blocks;
     {   // stride close to the golden ratio of n_blocks and coprime with it
         auto gcd = [](uint32_t a, uint32_t c) { while (c) { uint32_t t = a % c; a = c; c = t; } return a; };
@@ -230,17 +234,17 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const uint32_t v0 = pass * vpp, nv = std::min(vpp, n_views - v0);
         const ViewXform* d_views = (const ViewXform*)dev->views.ptr + v0;
-        b.counters = (uint32_t*)dev->counters.ptr + (size_t)pass * kCountersPerPass;
         hipEvent_t* ev = dev->profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
         if (ev) SR_HIP(hipEventRecord(ev[0], st));
-        launch_clear_vis(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples);
+        launch_begin_pass(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples, b.count_small, zero_words * 4,
+                          sg.d, dev->views.ptr, pass == 0 ? (size_t)n_views * sizeof(ViewXform) : 0);
+        if (pass == 0) { SR_HIP(hipEventRecord(sg.ev, st)); sg.in_flight = true; }
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        SR_HIP(hipMemsetAsync(b.count_small, 0, count_words * 4, st));
         launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0);
         if (ev) SR_HIP(hipEventRecord(ev[3], st));
-        launch_scan(st, b, nv * n_tiles, nv);
+        launch_scan(st, b, nv * n_tiles, nv, (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass);
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         launch_fill(st, g, b, m->n_tris, nv);
         if (ev) SR_HIP(hipEventRecord(ev[5], st));
@@ -254,7 +258,6 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[7], st));
     }
     SR_HIP(hipGetLastError());
-    SR_HIP(hipMemcpyAsync(tg->h_counters, dev->counters.ptr, (size_t)passes * kCountersPerPass * 4, hipMemcpyDeviceToHost, st));
     tg->passes = passes;
     tg->capacity_at_draw = dev->ref_capacity;
     tg->check_pending = true;

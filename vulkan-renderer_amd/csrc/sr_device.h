@@ -207,9 +207,11 @@ struct BinBuffers {
     uint32_t* tile_offset;    // [views*tiles + 1]: exclusive scan of count_small + count_large
     uint32_t* refs;           // [capacity]: triangle ids grouped by (view, tile)
     uint32_t ref_capacity;
+    uint32_t* pending;        // [views][blocks][block triangles]: ids of the triangles set-up hands to the binning kernel
+    uint32_t* pending_count;  // [views][blocks]
     BinRecord* records;       // [views][blocks][block triangles * kMaxSmallTiles]; each set-up block owns one segment
     uint32_t* block_count;    // [views][blocks]: records written by each set-up block
-    uint32_t* block_live;     // [views][blocks]: triangles that survived culling in each set-up block
+    uint32_t* block_live;     // [views][blocks]: pending triangles | micro-triangles resolved << 16, per set-up block
     uint32_t block_stride;    // coprime with n_blocks: hardware block i works on triangle block (i * block_stride) % n_blocks, so that
                               // blocks running at the same time touch different tiles (their per-tile atomics do not pile up)
     uint32_t n_blocks;        // set-up blocks per view

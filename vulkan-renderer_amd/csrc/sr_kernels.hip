@@ -21,13 +21,22 @@ __global__ __launch_bounds__(256) void split_positions_kernel(const float4* __re
 }
 
 // =================================================================================================
-// stage 0: clear the visibility buffer (depth 1.0, no triangle): 16 bytes per lane, grid-stride
+// stage 0: start of a pass.  Clears the visibility buffer (depth 1.0, no triangle; 16 bytes per lane,
+// grid-stride), zeroes the binning counters, and on the first pass of a draw pulls the per-view
+// transforms from pinned host memory -- so a draw issues kernels only, no small copies or memsets.
 // =================================================================================================
-__global__ __launch_bounds__(256) void clear_vis_kernel(ulonglong2* __restrict__ vis2, size_t n2, unsigned long long* __restrict__ tail)
+__global__ __launch_bounds__(256) void begin_pass_kernel(ulonglong2* __restrict__ vis2, size_t n2, unsigned long long* __restrict__ tail,
+                                                         uint4* __restrict__ zero4, size_t n_zero4,
+                                                         const uint4* __restrict__ views_src, uint4* __restrict__ views_dst, uint32_t n_views4)
 {
+    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x, gstride = (size_t)gridDim.x * 256u;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < n_views4; i += 256u) views_dst[i] = views_src[i];
+        if (tail && threadIdx.x == 0) *tail = kVisClear;
+    }
+    for (size_t i = gtid; i < n_zero4; i += gstride) zero4[i] = make_uint4(0u, 0u, 0u, 0u);
     const ulonglong2 c = make_ulonglong2(kVisClear, kVisClear);
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256u) vis2[i] = c;
-    if (tail && blockIdx.x == 0 && threadIdx.x == 0) *tail = kVisClear;
+    for (size_t i = gtid; i < n2; i += gstride) vis2[i] = c;
 }
 
 // =================================================================================================
@@ -159,29 +168,20 @@ __device__ inline void micro_resolve(const MicroEdges& e, uint32_t cov, int x0, 
     }
 }
 
+// Set-up: one lane handles kTrisPerThread triangles (all index loads first, then all vertex loads, so
+// a dozen independent gathers are in flight per lane).  Back faces, degenerate triangles and boxes
+// that contain no sample point are dropped; micro-triangles are resolved on the spot; whatever is
+// left is handed to the binning kernel through the block's own slice of the `pending` list (no
+// atomics: ballots and prefix counts).
 template <int S>
 __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                     FrameGeom g, BinBuffers b, unsigned long long* __restrict__ vis, uint32_t view0)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_key[kHashSize];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHashSize];
-    __shared__ uint32_t s_total[2];   // records, live triangles
+    __shared__ uint32_t s_wave[kTrisPerThread * 4];
+    __shared__ uint32_t s_micro[4];
     const uint32_t view = blockIdx.y;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * b.block_stride) % b.n_blocks);
-    const uint32_t lane = lane_id();
-    const uint64_t lanes_below = (1ull << lane) - 1ull;
-    const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
-    uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
-    uint32_t* count_large = b.count_large + (size_t)view * n_tiles;
-#pragma unroll
-    for (uint32_t k = 0; k < kHashSize / 1024u; ++k) {
-        reinterpret_cast<uint4*>(s_key)[tid + 256u * k] = make_uint4(kHashEmpty, kHashEmpty, kHashEmpty, kHashEmpty);
-        reinterpret_cast<uint4*>(s_cnt)[tid + 256u * k] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    if (tid < 2) s_total[tid] = 0u;
-
-    // all index loads first, then all vertex loads: 12 independent gathers in flight per lane
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const uint32_t blk = blockIdx.x;
     const int2* xy = sp.xy + (size_t)view * sp.n_verts;
     uint32_t tri[kTrisPerThread], i0[kTrisPerThread], i1[kTrisPerThread], i2[kTrisPerThread];
     bool in_range[kTrisPerThread];
@@ -195,39 +195,149 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
     int2 r0[kTrisPerThread], r1[kTrisPerThread], r2[kTrisPerThread];
 #pragma unroll
     for (uint32_t k = 0; k < kTrisPerThread; ++k) { r0[k] = xy[i0[k]]; r1[k] = xy[i1[k]]; r2[k] = xy[i2[k]]; }
-    __syncthreads();   // hash table initialised
 
-    // per triangle: tile span (0 records = culled); for small triangles the hash slot and the rank
-    // inside the slot's group of every covered tile
-    uint32_t nrec[kTrisPerThread], span[kTrisPerThread];
-    uint32_t slot[kTrisPerThread][kMaxSmallTiles], local[kTrisPerThread][kMaxSmallTiles];
-    uint32_t n_unproj = 0, n_live = 0, n_micro = 0, is_large = 0;
+    uint32_t n_unproj = 0, n_micro = 0;
     uint32_t micro_cov[kTrisPerThread], micro_box[kTrisPerThread];   // coverage bits; x0 | y0<<14 | npx<<28
+    bool pend[kTrisPerThread];
 #pragma unroll
     for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-        nrec[k] = 0; span[k] = 0; micro_cov[k] = 0; micro_box[k] = 0;
-        int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
+        micro_cov[k] = 0; micro_box[k] = 0; pend[k] = false;
         const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
         const int64_t area2 = (int64_t)(r1[k].x - r0[k].x) * (int64_t)(r2[k].y - r0[k].y) - (int64_t)(r2[k].x - r0[k].x) * (int64_t)(r1[k].y - r0[k].y);
         if (in_range[k] && bad > 0 && bad < 3) ++n_unproj;
-        bool live = false;
         if (in_range[k] && bad == 0 && area2 < 0) {
+            const int mnx = min(r0[k].x, min(r1[k].x, r2[k].x)), mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
+            const int mny = min(r0[k].y, min(r1[k].y, r2[k].y)), mxy = max(r0[k].y, max(r1[k].y, r2[k].y));
+            int x0, x1, y0, y1;
+            pixel_span<S>(mnx, mxx, x0, x1);
+            pixel_span<S>(mny, mxy, y0, y1);
+            x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+            y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+            const int npx = x1 - x0 + 1, npy = y1 - y0 + 1;
+            if (npx > 0 && npy > 0) {
+                if (npx * npy <= kMicroPixels && mxx - mnx < 16384 && mxy - mny < 16384) {
+                    micro_cov[k] = micro_coverage<S>(micro_edges(r0[k], r1[k], r2[k]), x0, y0, npx, npy);
+                    micro_box[k] = (uint32_t)x0 | ((uint32_t)y0 << 14) | ((uint32_t)npx << 28);
+                    if (micro_cov[k]) ++n_micro;
+                } else pend[k] = true;
+            }
+        }
+    }
+    // micro-triangles with a covered sample: fetch the three depths (all loads first), then resolve
+    {
+        const float2* zw = sp.zw + (size_t)view * sp.n_verts;
+        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
+        float z0[kTrisPerThread], z1[kTrisPerThread], z2[kTrisPerThread];
+#pragma unroll
+        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+            z0[k] = z1[k] = z2[k] = 0.0f;
+            if (micro_cov[k]) { z0[k] = zw[i0[k]].x; z1[k] = zw[i1[k]].x; z2[k] = zw[i2[k]].x; }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+            if (!micro_cov[k]) continue;
+            const int32_t A = -((r1[k].x - r0[k].x) * (r2[k].y - r0[k].y) - (r2[k].x - r0[k].x) * (r1[k].y - r0[k].y));
+            micro_resolve<S>(micro_edges(r0[k], r1[k], r2[k]), micro_cov[k], (int)(micro_box[k] & 16383u), (int)((micro_box[k] >> 14) & 16383u),
+                             (int)(micro_box[k] >> 28), z0[k], z1[k], z2[k], 1.0f / (float)A, tri[k], vis_view, g);
+        }
+    }
+    if (n_unproj) atomicAdd(&b.counters[2], n_unproj);   // triangles that would need clipping (rare)
+    // hand the remaining triangles to the binning kernel
+    uint64_t m[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        m[k] = __ballot(pend[k]);
+        if (lane == 0) s_wave[k * 4u + wave] = (uint32_t)__popcll(m[k]);
+    }
+    {
+        uint32_t w = n_micro;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w += (uint32_t)__shfl_down((int)w, o);
+        if (lane == 0) s_micro[wave] = w;
+    }
+    __syncthreads();
+    uint32_t run = 0;
+    uint32_t* slice = b.pending + ((size_t)view * b.n_blocks + blk) * kBlockTris;
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            if (w == wave && pend[k]) slice[run + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))] = tri[k];
+            run += s_wave[k * 4u + w];
+        }
+    }
+    if (tid == 0) {
+        b.pending_count[(size_t)view * b.n_blocks + blk] = run;
+        b.block_live[(size_t)view * b.n_blocks + blk] = run | ((s_micro[0] + s_micro[1] + s_micro[2] + s_micro[3]) << 16);
+    }
+}
+
+// Binning of the triangles set-up left pending.  Block b takes slice b of the pending list, in a
+// permuted order so that blocks running at the same time work on distant parts of the mesh.
+template <int S>
+__global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ idx, ScreenPlanes sp, FrameGeom g, BinBuffers b)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[kHashSize];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHashSize];
+    __shared__ uint32_t s_total;
+    const uint32_t view = blockIdx.y;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * b.block_stride) % b.n_blocks);
+    const uint32_t lane = lane_id();
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
+    const uint32_t n = b.pending_count[(size_t)view * b.n_blocks + blk];
+    if (tid == 0) b.block_count[(size_t)view * b.n_blocks + blk] = 0u;
+    if (n == 0) return;   // uniform over the block
+    uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
+    uint32_t* count_large = b.count_large + (size_t)view * n_tiles;
+#pragma unroll
+    for (uint32_t k = 0; k < kHashSize / 1024u; ++k) {
+        reinterpret_cast<uint4*>(s_key)[tid + 256u * k] = make_uint4(kHashEmpty, kHashEmpty, kHashEmpty, kHashEmpty);
+        reinterpret_cast<uint4*>(s_cnt)[tid + 256u * k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid == 0) s_total = 0u;
+
+    const uint32_t* slice = b.pending + ((size_t)view * b.n_blocks + blk) * kBlockTris;
+    const int2* xy = sp.xy + (size_t)view * sp.n_verts;
+    uint32_t tri[kTrisPerThread], i0[kTrisPerThread], i1[kTrisPerThread], i2[kTrisPerThread];
+    bool have[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        have[k] = k * 256u + tid < n;
+        tri[k] = have[k] ? slice[k * 256u + tid] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        i0[k] = i1[k] = i2[k] = 0u;
+        if (have[k]) { i0[k] = idx[3 * (size_t)tri[k]]; i1[k] = idx[3 * (size_t)tri[k] + 1]; i2[k] = idx[3 * (size_t)tri[k] + 2]; }
+    }
+    int2 r0[kTrisPerThread], r1[kTrisPerThread], r2[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        r0[k] = r1[k] = r2[k] = make_int2(0, 0);
+        if (have[k]) { r0[k] = xy[i0[k]]; r1[k] = xy[i1[k]]; r2[k] = xy[i2[k]]; }
+    }
+    __syncthreads();   // hash table initialised
+
+    // per triangle: tile span; for small triangles the hash slot and the rank inside the slot's group
+    // of every covered tile
+    uint32_t nrec[kTrisPerThread], span[kTrisPerThread];
+    uint32_t slot[kTrisPerThread][kMaxSmallTiles], local[kTrisPerThread][kMaxSmallTiles];
+    uint32_t is_large = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        nrec[k] = 0; span[k] = 0;
+        int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
+        bool live = false;
+        if (have[k]) {   // set-up already established: projectable, front-facing, non-empty pixel span
             int x0, x1, y0, y1;
             pixel_span<S>(min(r0[k].x, min(r1[k].x, r2[k].x)), max(r0[k].x, max(r1[k].x, r2[k].x)), x0, x1);
             pixel_span<S>(min(r0[k].y, min(r1[k].y, r2[k].y)), max(r0[k].y, max(r1[k].y, r2[k].y)), y0, y1);
             x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
             y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
-            const int npx = x1 - x0 + 1, npy = y1 - y0 + 1;
-            const int bw = max(r0[k].x, max(r1[k].x, r2[k].x)) - min(r0[k].x, min(r1[k].x, r2[k].x));
-            const int bh = max(r0[k].y, max(r1[k].y, r2[k].y)) - min(r0[k].y, min(r1[k].y, r2[k].y));
-            if (npx > 0 && npy > 0 && npx * npy <= kMicroPixels && bw < 16384 && bh < 16384) {
-                // micro-triangle: resolved below without binning (or dropped if it covers no sample)
-                micro_cov[k] = micro_coverage<S>(micro_edges(r0[k], r1[k], r2[k]), x0, y0, npx, npy);
-                micro_box[k] = (uint32_t)x0 | ((uint32_t)y0 << 14) | ((uint32_t)npx << 28);
-                if (micro_cov[k]) ++n_micro;
-            } else if (x0 <= x1 && y0 <= y1) {
+            if (x0 <= x1 && y0 <= y1) {
                 live = true;
-                ++n_live;
                 tx0 = (x0 - g.rx) >> g.tile_log2; ty0 = (y0 - g.ry) >> g.tile_log2;
                 const int tx1 = (x1 - g.rx) >> g.tile_log2, ty1 = (y1 - g.ry) >> g.tile_log2;
                 span[k] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
@@ -263,7 +373,7 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
         if (small) {
             nrec[k] = (uint32_t)(nx * ny);
 #pragma unroll
-            for (uint32_t j = 1; j < kMaxSmallTiles; ++j) {   // further tiles of triangles that straddle a tile border (few)
+            for (uint32_t j = 1; j < kMaxSmallTiles; ++j) {   // further tiles of triangles that straddle a tile border
                 slot[k][j] = kHashSize; local[k][j] = 0;
                 if (j < nrec[k]) {
                     const uint32_t tile = (uint32_t)((ty0 + (int)(j / (uint32_t)nx)) * g.tiles_x + tx0 + (int)(j % (uint32_t)nx));
@@ -282,25 +392,6 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
                 for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&count_large[ty * g.tiles_x + tx], 1u);
         }
     }
-    // micro-triangles with a covered sample: fetch the three depths (all loads first), then resolve
-    {
-        const float2* zw = sp.zw + (size_t)view * sp.n_verts;
-        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
-        float z0[kTrisPerThread], z1[kTrisPerThread], z2[kTrisPerThread];
-#pragma unroll
-        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-            z0[k] = z1[k] = z2[k] = 0.0f;
-            if (micro_cov[k]) { z0[k] = zw[i0[k]].x; z1[k] = zw[i1[k]].x; z2[k] = zw[i2[k]].x; }
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-            if (!micro_cov[k]) continue;
-            const int32_t A = -((r1[k].x - r0[k].x) * (r2[k].y - r0[k].y) - (r2[k].x - r0[k].x) * (r1[k].y - r0[k].y));
-            micro_resolve<S>(micro_edges(r0[k], r1[k], r2[k]), micro_cov[k], (int)(micro_box[k] & 16383u), (int)((micro_box[k] >> 14) & 16383u),
-                             (int)(micro_box[k] >> 28), z0[k], z1[k], z2[k], 1.0f / (float)A, tri[k], vis_view, g);
-        }
-    }
-    if (n_unproj) atomicAdd(&b.counters[2], n_unproj);   // triangles that would need clipping (rare)
     // place of this lane's records inside the block's segment (any order will do): wave prefix sum
     uint32_t first[kTrisPerThread];
     {
@@ -310,12 +401,8 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
         uint32_t incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
-        uint32_t live_sum = n_live | (n_micro << 16);   // two 16-bit counts per lane, summed together (a block has 1024 triangles)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) live_sum += (uint32_t)__shfl_down((int)live_sum, o);
         uint32_t wave_base = 0;
-        if (lane == 63u) wave_base = atomicAdd(&s_total[0], incl);
-        if (lane == 0u && live_sum) atomicAdd(&s_total[1], live_sum);
+        if (lane == 63u) wave_base = atomicAdd(&s_total, incl);
         wave_base = (uint32_t)__shfl((int)wave_base, 63);
         uint32_t run = wave_base + incl - mine;
 #pragma unroll
@@ -349,10 +436,7 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
                 }
         }
     }
-    if (tid == 0) {
-        b.block_count[(size_t)view * b.n_blocks + blk] = s_total[0];
-        b.block_live[(size_t)view * b.n_blocks + blk] = s_total[1];
-    }
+    if (tid == 0) b.block_count[(size_t)view * b.n_blocks + blk] = s_total;
 }
 
 // =================================================================================================
@@ -360,9 +444,12 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
 // =================================================================================================
 __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ count_a, const uint32_t* __restrict__ count_b, uint32_t n,
                                                     uint32_t* __restrict__ offset, uint32_t* __restrict__ counters,
-                                                    const uint32_t* __restrict__ block_live, uint32_t n_block_counts)
+                                                    const uint32_t* __restrict__ block_live, uint32_t n_block_counts,
+                                                    uint32_t* __restrict__ host_counters)
 {
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t s_sum[2];
+    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0u;
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t beg = min(tid * per, n), end = min(beg + per, n);
@@ -383,8 +470,14 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
     uint32_t surv = 0, micro = 0;
     for (uint32_t i = tid; i < n_block_counts; i += 1024u) { const uint32_t v = block_live[i]; surv += v & 0xFFFFu; micro += v >> 16; }
     for (int o = 32; o > 0; o >>= 1) { surv += (uint32_t)__shfl_down((int)surv, o); micro += (uint32_t)__shfl_down((int)micro, o); }
-    if ((tid & 63u) == 0u && surv) atomicAdd(&counters[3], surv);
-    if ((tid & 63u) == 0u && micro) atomicAdd(&counters[4], micro);
+    if ((tid & 63u) == 0u) { atomicAdd(&s_sum[0], surv); atomicAdd(&s_sum[1], micro); }
+    __syncthreads();
+    if (tid == 0) {
+        // results of the pass for the host, written straight into pinned host memory (read after the
+        // stream has been synchronised): total references, -, unprojectable, binned, direct
+        host_counters[0] = part[1023]; host_counters[1] = 0u; host_counters[2] = counters[2];
+        host_counters[3] = s_sum[0]; host_counters[4] = s_sum[1];
+    }
 }
 
 // =================================================================================================
@@ -970,12 +1063,12 @@ void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* 
     split_positions_kernel<<<div_up(n, 256), 256, 0, st>>>((const float4*)aos, n, px, py, pz);
 }
 
-void launch_clear_vis(hipStream_t st, uint64_t* vis, size_t n)
+void launch_begin_pass(hipStream_t st, uint64_t* vis, size_t n, void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes)
 {
-    if (!n) return;
     const size_t n2 = n / 2;
     const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>((n2 + 255) / 256, 1), 256 * 16);
-    clear_vis_kernel<<<blocks, 256, 0, st>>>((ulonglong2*)vis, n2, (n & 1) ? (unsigned long long*)vis + (n - 1) : nullptr);
+    begin_pass_kernel<<<blocks, 256, 0, st>>>((ulonglong2*)vis, n2, (n & 1) ? (unsigned long long*)vis + (n - 1) : nullptr,
+                                              (uint4*)zero16, zero_bytes / 16, (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
 }
 
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
@@ -990,13 +1083,18 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
 {
     if (!n_tris || !n_views) return;
     const dim3 grid(b.n_blocks, n_views);
-    if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
-    else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
+    if (g.samples == 1) {
+        setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
+        bin_kernel<1><<<grid, 256, 0, st>>>(idx, sp, g, b);
+    } else {
+        setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
+        bin_kernel<4><<<grid, 256, 0, st>>>(idx, sp, g, b);
+    }
 }
 
-void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views)
+void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters)
 {
-    scan_kernel<<<1, 1024, 0, st>>>(b.count_small, b.count_large, n_entries, b.tile_offset, b.counters, b.block_live, b.n_blocks * n_views);
+    scan_kernel<<<1, 1024, 0, st>>>(b.count_small, b.count_large, n_entries, b.tile_offset, b.counters, b.block_live, b.n_blocks * n_views, host_counters);
 }
 
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views)
