@@ -719,10 +719,10 @@ __device__ inline int wrap_repeat(int i, int n) { const int m = i % n; return m 
 
 // bilinear fetch of NCH leading channels from one level
 template <int NCH>
-__device__ inline void sample_level(const TexDesc& t, int level, float s, float tt, const float* dec, float* o)
+__device__ inline void sample_level(const TexDesc& t, const uint32_t* lvl, int level, float s, float tt, const float* dec, float* o)
 {
     const int wl = max(t.w >> level, 1), hl = max(t.h >> level, 1);
-    const uint32_t* base = t.texels + t.level_off[level];
+    const uint32_t* base = t.texels + lvl[level];   // LDS copy of t.level_off (a per-lane index into kernel arguments would be a memory load)
     const float u = s * (float)wl - 0.5f, v = tt * (float)hl - 0.5f;
     float fu = floorf(u), fv = floorf(v);
     const float a = u - fu, b = v - fv;
@@ -751,7 +751,7 @@ __device__ inline void sample_level(const TexDesc& t, int level, float s, float 
 
 // texture() with the 2x2-quad differences supplied; isotropic LOD, trilinear, REPEAT
 template <int NCH>
-__device__ inline void sample_texture(const TexDesc& t, float s, float tt, float dsdx, float dtdx, float dsdy, float dtdy,
+__device__ inline void sample_texture(const TexDesc& t, const uint32_t* lvl, float s, float tt, float dsdx, float dtdx, float dsdy, float dtdy,
                                       const float* dec, float* o)
 {
     const float mux = dsdx * (float)t.w, mvx = dtdx * (float)t.h;
@@ -766,14 +766,14 @@ __device__ inline void sample_texture(const TexDesc& t, float s, float tt, float
     const float dhi = floorf(d), delta = d - dhi;
     const int lhi = (int)dhi, llo = min(lhi + 1, t.levels - 1);
     float chi[NCH];
-    sample_level<NCH>(t, lhi, s, tt, dec, chi);
+    sample_level<NCH>(t, lvl, lhi, s, tt, dec, chi);
     if (delta == 0.0f) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) o[c] = chi[c];
         return;
     }
     float clo[NCH];
-    sample_level<NCH>(t, llo, s, tt, dec, clo);
+    sample_level<NCH>(t, lvl, llo, s, tt, dec, clo);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) o[c] = (1.0f - delta) * chi[c] + delta * clo[c];
 }
@@ -874,7 +874,7 @@ struct FragParams {
 // to vertex 0 (exact for triangles up to a few hundred pixels, 2^-24 relative otherwise); the values
 // at the other pixels of the 2x2 quad follow from their screen-space gradients.
 __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, size_t sv_base, uint32_t tri, int x, int y,
-                                       const float* dec, const float* thr)
+                                       const float* dec, const float* thr, const uint32_t* lvl /* [3][kMaxMipLevels] */)
 {
     const uint32_t i0 = p.idx[3 * (size_t)tri], i1 = p.idx[3 * (size_t)tri + 1], i2 = p.idx[3 * (size_t)tri + 2];
     const float4 a0 = p.verts[2 * (size_t)i0], b0 = p.verts[2 * (size_t)i0 + 1];
@@ -921,9 +921,9 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
 #pragma unroll
     for (int k = 0; k < 3; ++k) { wp[k] = fmaf(p2, w2[k], fmaf(p1, w1[k], p0 * w0[k])); N[k] = fmaf(p2, n2[k], fmaf(p1, n1[k], p0 * n0[k])); }
     float alb[3], met[1], rgh[1], rgb[3];
-    sample_texture<3>(p.albedo, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
-    sample_texture<1>(p.metallic, u, v, dudx, dvdx, dudy, dvdy, dec, met);
-    sample_texture<1>(p.roughness, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+    sample_texture<3>(p.albedo, lvl, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
+    sample_texture<1>(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, met);
+    sample_texture<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
     fragment_main(wp, N, vx.cam, alb, met[0], rgh[0], rgb);
     const uint32_t R = (uint32_t)srgb_encode8(rgb[0] > 1.0f ? 1.0f : rgb[0], thr);
     const uint32_t G = (uint32_t)srgb_encode8(rgb[1] > 1.0f ? 1.0f : rgb[1], thr);
@@ -936,9 +936,14 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
 {
     __shared__ float s_dec[256];
     __shared__ float s_thr[256];
+    __shared__ uint32_t s_lvl[3 * kMaxMipLevels];
     const uint32_t tid = threadIdx.y * 32u + threadIdx.x;
     s_dec[tid] = p.tab.decode[tid];
     s_thr[tid] = tid < 255u ? p.tab.thresh[tid] : 3.0e38f;
+    if (tid < 3u * kMaxMipLevels) {
+        const uint32_t m = tid / kMaxMipLevels, l = tid % kMaxMipLevels;
+        s_lvl[tid] = m == 0 ? p.albedo.level_off[l] : m == 1 ? p.metallic.level_off[l] : p.roughness.level_off[l];
+    }
     __syncthreads();
     const int lx = (int)(blockIdx.x * 32u + threadIdx.x), ly = (int)(blockIdx.y * 8u + threadIdx.y);
     const uint32_t view = blockIdx.z;
@@ -963,7 +968,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
             for (int k = 0; k < s; ++k) if (k == prev) c = col[k];
             col[s] = c;
         } else {
-            col[s] = shade_pixel(p, vx, sv, ids[s], x, y, s_dec, s_thr);
+            col[s] = shade_pixel(p, vx, sv, ids[s], x, y, s_dec, s_thr, s_lvl);
         }
     }
     uint32_t outc;
