@@ -72,7 +72,7 @@ typedef struct sr_draw_stats {
 
 /* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */
 typedef struct sr_stage_times {
-    float clear_ms, vertex_ms, setup_ms, scan_ms, fill_ms, raster_ms, fragment_ms, total_ms;
+    float clear_ms, vertex_ms, setup_ms, bin_ms, scan_ms, fill_ms, raster_ms, fragment_ms, total_ms;
 } sr_stage_times;
 
 /* ---- device: replaces vkh::GPUDevice, src/vulkan_helper/gpu_device.hpp:42-48 (constructed at

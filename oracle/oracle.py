@@ -52,6 +52,8 @@ def lib():
         L.sro_sample.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]
         L.sro_fragment_main.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_void_p]
         L.sro_perspective.argtypes = [C.c_float] * 4 + [C.c_void_p]
+        L.sro_srgb_encode8.argtypes = [C.c_float]
+        L.sro_srgb_encode8.restype = C.c_int
         assert L.sro_draw_args_size() == C.sizeof(_DrawArgs)
         _lib = L
     return _lib
@@ -66,6 +68,10 @@ def srgb_tables():
     thr = np.empty(255, np.float32)
     lib().sro_srgb_tables(_p(dec), _p(thr))
     return dec, thr
+
+
+def srgb_encode8(x: float) -> int:
+    return lib().sro_srgb_encode8(float(x))
 
 
 def look_at(eye, center, up) -> np.ndarray:

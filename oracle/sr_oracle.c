@@ -90,6 +90,12 @@ static int unorm_encode8(float x)
     return (int)rintf(x * 255.0f);
 }
 
+SRO_API int sro_srgb_encode8(float x)
+{
+    pthread_once(&g_once, init_tables);
+    return srgb_encode8(x);
+}
+
 SRO_API void sro_srgb_tables(float* decode256, float* thresh255)
 {
     pthread_once(&g_once, init_tables);

@@ -1,0 +1,89 @@
+"""CPU-side checks of the boundary: the shared library loads and exports every symbol the header
+declares (no compute calls), and the host-side scene helpers behave."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "softraster.h")).read()
+    return re.findall(r"SR_API\s+[\w\s\*]+?\b(sr_\w+)\s*\(", text)
+
+
+def test_header_symbols_are_exported(sr):
+    names = declared_symbols()
+    assert len(names) >= 20 and set(names) == set(sr.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(sr.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/softraster.h but not exported"
+
+
+def test_status_strings_without_a_gpu(sr):
+    lib = sr.load_library()
+    assert lib.sr_status_string(0) == b"ok"
+    assert b"gfx950" in lib.sr_status_string(-6)
+    s = sr.SamplerDesc()
+    lib.sr_sampler_default(ctypes.byref(s))
+    # the sampler src/texture.cpp:246-263 creates: LOD clamp [0, mip_levels], no bias, 16x anisotropy
+    assert (s.min_lod, s.mip_lod_bias, s.max_anisotropy) == (0.0, 0.0, 16.0) and s.max_lod < 0
+
+
+def test_no_silent_cpu_path(sr):
+    """Without a GPU the product refuses to create a device instead of rendering on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sr.SoftRasterError) as e:
+        sr.Device(0)
+    assert e.value.status == -6
+
+
+def test_product_does_not_import_the_oracle():
+    """The checker is test infrastructure: nothing under the package imports, includes, links or loads it."""
+    pkg = os.path.join(ROOT, "vulkan-renderer_amd")
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|sr_oracle|libsr_oracle|#include\s+\"[^\"]*oracle|oracle/)")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not pat.search(text), f"{f} refers to the oracle"
+
+
+def test_uv_sphere_counts_and_winding(sr):
+    v, i = sr.scene.uv_sphere(88, 88)
+    assert v.shape == (89 * 89, 8) and i.size // 3 == 15488       # stand-in for the reference's bundled helmet
+    assert np.allclose(np.linalg.norm(v[:, :3], axis=1), 1.0, atol=1e-6) and np.array_equal(v[:, :3], v[:, 3:6])
+    assert v[:, 6:8].min() == 0.0 and v[:, 6:8].max() == 1.0
+    t = i.reshape(-1, 3).astype(np.int64)
+    p0, p1, p2 = v[t[:, 0], :3], v[t[:, 1], :3], v[t[:, 2], :3]
+    n = np.cross(p1 - p0, p2 - p0)
+    area = np.linalg.norm(n, axis=1)
+    ok = area > 1e-9
+    assert (~ok).sum() == 2 * 88                                   # one degenerate triangle per quad at each pole
+    assert ((n[ok] * (p0[ok] + p1[ok] + p2[ok])).sum(axis=1) > 0).all()   # counter-clockwise seen from outside
+    # the benchmark meshes: 10 M and 50 M triangles
+    assert 2 * 2500 * 2000 == 10_000_000 and 2 * 5000 * 5000 == 50_000_000
+
+
+def test_uniform_block_layout(sr):
+    ubo = sr.scene.default_camera_ubo(800, 600)
+    assert ubo.dtype == np.float32 and ubo.nbytes == 208
+    assert np.array_equal(ubo[0:16].reshape(4, 4), np.eye(4, dtype=np.float32))      # model at 0
+    assert ubo[16 + 14] == pytest.approx(-3.4641016)                                   # view column 3, row 2 at byte 64 + 56
+    assert ubo[32 + 11] == -1.0 and ubo[32 + 15] == 0.0                                # proj[2][3] = -1 (column-major)
+    assert np.array_equal(ubo[48:51], np.array([2, 2, 2], np.float32)) and ubo[51] == 0
+
+
+def test_orbit_cameras(sr):
+    e0 = sr.scene.orbit_eye(0, 64)
+    assert np.allclose(e0, (2, 2, 2), atol=1e-6)
+    eyes = np.stack([sr.scene.orbit_eye(k, 64) for k in range(64)])
+    assert np.allclose(np.linalg.norm(eyes, axis=1), np.sqrt(12.0), atol=1e-5)          # all on the reference's orbit sphere
+    assert len({tuple(np.round(e, 4)) for e in eyes}) == 64
+    u = sr.scene.orbit_ubos(4, 1920, 1080, first=8, total=64)
+    assert u.shape == (4, 52) and np.allclose(u[0, 48:51], eyes[8], atol=1e-6)

@@ -46,7 +46,7 @@ struct DeviceBuffer {
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
 };
 
-constexpr int kNumStageEvents = 8;   // start, clear, vertex, setup, scan, fill, raster, fragment
+constexpr int kNumStageEvents = 9;   // start, clear, vertex, setup, bin, scan, fill, raster, fragment
 constexpr int kCountersPerPass = 8;  // total refs, dropped refs, unprojectable triangles, binned triangles, micro-triangles, spare
 
 }  // namespace
@@ -242,20 +242,21 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0);
-        if (ev) SR_HIP(hipEventRecord(ev[3], st));
-        launch_scan(st, b, nv * n_tiles, nv, (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass);
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr);
+        if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
-        launch_fill(st, g, b, m->n_tris, nv);
+        launch_scan(st, b, nv * n_tiles, nv, (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass);
         if (ev) SR_HIP(hipEventRecord(ev[5], st));
-        launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv);
+        launch_fill(st, g, b, m->n_tris, nv);
         if (ev) SR_HIP(hipEventRecord(ev[6], st));
+        launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv);
+        if (ev) SR_HIP(hipEventRecord(ev[7], st));
         FragLaunch f{};
         f.idx = m->d_idx; f.verts_aos = m->d_aos; f.screen = sp; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv;
         launch_fragment(st, f);
-        if (ev) SR_HIP(hipEventRecord(ev[7], st));
+        if (ev) SR_HIP(hipEventRecord(ev[8], st));
     }
     SR_HIP(hipGetLastError());
     tg->passes = passes;
@@ -625,13 +626,13 @@ int sr_profile_get(sr_device dev, sr_stage_times* out)
     float* f = &out->clear_ms;
     for (size_t p = 0; p < dev->events_used / kNumStageEvents; ++p) {
         hipEvent_t* ev = &dev->events[p * kNumStageEvents];
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < 8; ++k) {
             float ms = 0.0f;
             SR_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             f[k] += ms;
         }
         float ms = 0.0f;
-        SR_HIP(hipEventElapsedTime(&ms, ev[0], ev[7]));
+        SR_HIP(hipEventElapsedTime(&ms, ev[0], ev[8]));
         out->total_ms += ms;
     }
     return SR_OK;

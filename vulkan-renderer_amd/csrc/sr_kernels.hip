@@ -1084,17 +1084,15 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
 }
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
-                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0)
+                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between)
 {
     if (!n_tris || !n_views) return;
     const dim3 grid(b.n_blocks, n_views);
-    if (g.samples == 1) {
-        setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
-        bin_kernel<1><<<grid, 256, 0, st>>>(idx, sp, g, b);
-    } else {
-        setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
-        bin_kernel<4><<<grid, 256, 0, st>>>(idx, sp, g, b);
-    }
+    if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
+    else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
+    if (between) (void)hipEventRecord(between, st);
+    if (g.samples == 1) bin_kernel<1><<<grid, 256, 0, st>>>(idx, sp, g, b);
+    else bin_kernel<4><<<grid, 256, 0, st>>>(idx, sp, g, b);
 }
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters)

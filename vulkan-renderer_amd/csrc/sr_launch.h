@@ -25,7 +25,7 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
 // vis: n words to clear; zero16/zero_bytes: 16-byte aligned block to zero; views_*: optional 16-byte aligned copy (0 bytes = none)
 void launch_begin_pass(hipStream_t st, uint64_t* vis, size_t n, void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes);
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
-                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0);
+                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between /* recorded between set-up and binning, may be null */);
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters);
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views);
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,

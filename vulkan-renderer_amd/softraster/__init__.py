@@ -55,7 +55,7 @@ class DrawStats(C.Structure):
 
 
 class StageTimes(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("clear_ms", "vertex_ms", "setup_ms", "scan_ms", "fill_ms", "raster_ms", "fragment_ms", "total_ms")]
+    _fields_ = [(n, C.c_float) for n in ("clear_ms", "vertex_ms", "setup_ms", "bin_ms", "scan_ms", "fill_ms", "raster_ms", "fragment_ms", "total_ms")]
 
     def as_dict(self):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
