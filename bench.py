@@ -63,12 +63,71 @@ def frame_bytes_reference_model(st):
     return (V * 28) + (T * 12 + V * 16 + R * 4) + (R * 4 + R * 12 + V * 16 + P * S * 8) + (P * S * 8 + F * 108 + X * 4 + P * 4)
 
 
+def sort_first(args, sr, rank, local_rank, world):
+    """BASELINE config 4: the 10 M-triangle scene at 7680x4320, the frame split into horizontal bands over
+    the ranks (mesh and textures replicated), finished BGRA8 bands gathered on rank 0 over RCCL."""
+    import torch
+    import torch.distributed as dist
+    from softraster import distributed as d
+    W, H = 7680, 4320
+    verts, idx = sr.scene.uv_sphere(2500, 2000)
+    images = [sr.scene.albedo_pattern(4096), None, sr.scene.gray_map(2048, 2048, 0, 254), sr.scene.gray_map(2048, 2048, 72, 255)]
+    ubo = sr.scene.default_camera_ubo(W, H)
+    torch.cuda.set_device(local_rank)
+    dev = sr.Device(local_rank)
+    mesh = sr.create_mesh_from_data(dev, verts, idx)
+    tex = [sr.create_texture(dev, im) if im is not None else None for im in images]
+    bands = d.split_bands(W, H, world)
+    band = bands[rank]
+    out = torch.empty((band[3], band[2], 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
+    tgt = sr.RenderTarget(dev, W, H, samples=1, n_views=1, rect=band)
+    tgt.bind_color(out.data_ptr())
+
+    def step():
+        sr.draw(dev, tgt, mesh, ubo, tex)
+        dev.synchronize()
+        return d.gather_bands(out, bands, rank, dst=0) if world > 1 else out
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        T = idx.size // 3
+        print(json.dumps({
+            "metric": "Mtris/s, 7680x4320 frame of a 10M-triangle mesh split sort-first over the GPUs", "value": round(T * args.steps / elapsed / 1e6, 2),
+            "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c4_8k_sort_first", "width": W, "height": H, "triangles": T, "bands": bands,
+                       "composite": "torch.distributed gather of BGRA8 bands (RCCL)" if world > 1 else "none"},
+            "frames_per_s": round(args.steps / elapsed, 2)}), flush=True)
+    for t_ in tex:
+        if t_ is not None:
+            t_.destroy()
+    tgt.destroy(); mesh.destroy(); dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3_4k_10Mtri", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="views", choices=["views", "sortfirst"],
+                    help="views: every rank draws its own camera of the workload (weak scaling, no collective); "
+                         "sortfirst: one 7680x4320 frame split into bands over the ranks, bands gathered on rank 0 (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -86,6 +145,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import softraster as sr
+    if args.mode == "sortfirst":
+        return sort_first(args, sr, rank, local_rank, world)
     W, H, SX, SY, alb_size, map_size = WORKLOADS[args.workload]
     verts, idx = sr.scene.uv_sphere(SX, SY)
     images = [sr.scene.albedo_pattern(alb_size), None, sr.scene.gray_map(map_size, map_size, 0, 254), sr.scene.gray_map(map_size, map_size, 72, 255)]

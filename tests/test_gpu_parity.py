@@ -166,3 +166,50 @@ def test_golden_fixtures(sr, device):
         g = np.load(make_golden.path_of(name))
         got = util.gpu_render(sr, device, sc["verts"], sc["idx"], sc["images"], sc["ubo"], sc["width"], sc["height"], sc["samples"])[0]
         _check_view(got, {"tri": g["tri"], "depth": g["depth"], "bgra": g["bgra"]})
+
+
+def test_cpp_host_app_matches_python_host(sr, device, tmp_path):
+    """The C++ mirror of the reference's host API (vulkan-renderer_amd/host) drives the same library:
+    its frame equals the Python host's up to the sphere's last-bit vertex differences."""
+    import os
+    import subprocess
+    app = os.path.join(os.path.dirname(sr.LIB_PATH), "headless_app")
+    assert os.path.exists(app), "build it with __graft_entry__.build()"
+    out = tmp_path / "frame.ppm"
+    subprocess.run([app, "320", "240", "48", "32", str(out)], check=True, timeout=120)
+    data = out.read_bytes()
+    header, rest = data.split(b"\n255\n", 1)
+    assert header == b"P6\n320 240"
+    rgb = np.frombuffer(rest, np.uint8).reshape(240, 320, 3)
+    verts, idx = sr.scene.uv_sphere(48, 32)
+    images = [sr.scene.albedo_pattern(2048), sr.scene.constant_rgba(64, 64, (128, 128, 255, 255)),
+              sr.scene.gray_map(2048, 2048, 0, 254), sr.scene.gray_map(2048, 2048, 72, 255)]
+    got = util.gpu_render(sr, device, verts, idx, images, sr.scene.default_camera_ubo(320, 240), 320, 240)[0]
+    frac, worst = util.color_match_fraction(rgb, got["bgra"][..., [2, 1, 0]], 2)
+    assert frac >= 0.995, (frac, worst)
+
+
+def test_colour_bound_to_caller_memory(sr, oracle, device):
+    """sr_target_bind_color: the frame lands in a torch tensor (what the sort-first composite hands to RCCL)."""
+    import torch
+    from softraster import distributed as d
+    verts, idx = sr.scene.uv_sphere(32, 24)
+    images = sr.scene.material_textures(64)
+    ubo = sr.scene.default_camera_ubo(256, 192)
+    mesh = sr.create_mesh_from_data(device, verts, idx)
+    tex = [sr.create_texture(device, im) for im in images]
+    bands = d.split_bands(256, 192, 3)
+    parts = []
+    for band in bands:
+        t, tgt = d.render_band_to_tensor(sr, device, mesh, tex, ubo, 256, 192, band)
+        parts.append(t.cpu().numpy())
+        tgt.destroy()
+    frame = np.concatenate(parts, axis=0)
+    ref = oracle.draw(ubo, verts, idx, images, 256, 192)
+    frac, worst = util.color_match_fraction(frame, ref["bgra"], 1)
+    assert frac >= 0.999, (frac, worst)
+    full = util.gpu_render(sr, device, verts, idx, images, ubo, 256, 192, textures=tex)[0]
+    assert np.array_equal(frame, full["bgra"])       # bands composite to the single-target frame bit for bit
+    for t in tex:
+        t.destroy()
+    mesh.destroy()

@@ -1,0 +1,185 @@
+// C++ host API of the draw path, shaped like the reference's so that its application code ports by
+// changing includes: vkh::GPUDevice (src/vulkan_helper/gpu_device.hpp:23-110), Vertex / StaticMesh /
+// create_mesh_from_data (src/mesh.hpp:18-72), Texture / create_texture / destroy_texture
+// (src/texture.hpp:9-24), UniformBufferObject (src/main.cpp:50-55) and the GLM camera helpers the
+// reference calls (src/main.cpp:992-997).  Everything forwards to the C ABI in include/softraster.h;
+// failures follow the reference's application-level convention (VKH_CHECK, src/vulkan_helper/check.hpp:8-15):
+// print file:line and abort.
+#pragma once
+
+#include <softraster.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#define SRH_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        const int srh_status_ = (expr);                                                                   \
+        if (srh_status_ != SR_OK) {                                                                       \
+            std::fprintf(stderr, "[%s:%d] %s failed: %s (%s)\n", __FILE__, __LINE__, #expr,               \
+                         sr_status_string(srh_status_), sr_last_error_string());                          \
+            std::abort();                                                                                 \
+        }                                                                                                 \
+    } while (0)
+
+// ---- the small part of GLM the reference uses -----------------------------------------------------
+struct vec2 { float x, y; };
+struct vec3 { float x, y, z; };
+struct mat4 { float m[16]; };   // column-major, like glm::mat4
+
+inline vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline vec3 cross(vec3 a, vec3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline vec3 normalize(vec3 a) { const float i = 1.0f / std::sqrt(dot(a, a)); return {a.x * i, a.y * i, a.z * i}; }
+inline float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+inline mat4 identity() { mat4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+
+// glm::lookAt, right-handed
+inline mat4 look_at(vec3 eye, vec3 center, vec3 up)
+{
+    const vec3 f = normalize(center - eye), s = normalize(cross(f, up)), u = cross(s, f);
+    mat4 r = identity();
+    r.m[0] = s.x; r.m[4] = s.y; r.m[8] = s.z; r.m[12] = -dot(s, eye);
+    r.m[1] = u.x; r.m[5] = u.y; r.m[9] = u.z; r.m[13] = -dot(u, eye);
+    r.m[2] = -f.x; r.m[6] = -f.y; r.m[10] = -f.z; r.m[14] = dot(f, eye);
+    return r;
+}
+// glm::perspective with GLM_FORCE_DEPTH_ZERO_TO_ONE, right-handed (src/main.cpp:4-5)
+inline mat4 perspective(float fovy, float aspect, float z_near, float z_far)
+{
+    const float t = std::tan(fovy / 2.0f);
+    mat4 r{};
+    r.m[0] = 1.0f / (aspect * t);
+    r.m[5] = 1.0f / t;
+    r.m[10] = z_far / (z_near - z_far);
+    r.m[11] = -1.0f;
+    r.m[14] = -(z_far * z_near) / (z_far - z_near);
+    return r;
+}
+
+struct UniformBufferObject {   // 204 bytes, memcpy'd per frame by the reference (src/main.cpp:1002)
+    mat4 model;
+    mat4 view;
+    mat4 proj;
+    vec3 camera_pos;
+};
+static_assert(sizeof(UniformBufferObject) == 204, "layout of src/main.cpp:50-55");
+
+struct Vertex {                // 32 bytes: the vertex input layout of src/mesh.hpp:18-54
+    vec3 pos;
+    vec3 normal;
+    vec2 tex_coord;
+};
+static_assert(sizeof(Vertex) == 32, "stride of src/mesh.hpp:28");
+
+namespace vkh {
+
+class GPUDevice {
+public:
+    explicit GPUDevice(int hip_ordinal = 0) { SRH_CHECK(sr_device_create(hip_ordinal, &device_)); }
+    ~GPUDevice() noexcept { sr_device_destroy(device_); }
+    GPUDevice(const GPUDevice&) = delete;
+    GPUDevice& operator=(const GPUDevice&) = delete;
+    GPUDevice(GPUDevice&&) = delete;
+    GPUDevice& operator=(GPUDevice&&) = delete;
+    void wait_idle() noexcept { sr_device_synchronize(device_); }
+    [[nodiscard]] sr_device device() const noexcept { return device_; }
+
+private:
+    sr_device device_ = nullptr;
+};
+
+}  // namespace vkh
+
+class StaticMesh {             // move-only owner, like the reference's UniqueBuffer pair
+public:
+    StaticMesh() = default;
+    StaticMesh(sr_device d, sr_mesh m, std::uint32_t n) : indices_size(n), device_(d), mesh_(m) {}
+    ~StaticMesh() { if (mesh_) sr_mesh_destroy(device_, mesh_); }
+    StaticMesh(StaticMesh&& o) noexcept : indices_size(o.indices_size), device_(o.device_), mesh_(std::exchange(o.mesh_, nullptr)) {}
+    StaticMesh& operator=(StaticMesh&& o) noexcept
+    {
+        if (this != &o) { if (mesh_) sr_mesh_destroy(device_, mesh_); device_ = o.device_; mesh_ = std::exchange(o.mesh_, nullptr); indices_size = o.indices_size; }
+        return *this;
+    }
+    StaticMesh(const StaticMesh&) = delete;
+    StaticMesh& operator=(const StaticMesh&) = delete;
+    [[nodiscard]] sr_mesh handle() const noexcept { return mesh_; }
+    std::uint32_t indices_size = 0;
+
+private:
+    sr_device device_ = nullptr;
+    sr_mesh mesh_ = nullptr;
+};
+
+[[nodiscard]] inline StaticMesh create_mesh_from_data(vkh::GPUDevice& device, const std::vector<Vertex>& vertices,
+                                                      const std::vector<std::uint32_t>& indices)
+{
+    sr_mesh m = nullptr;
+    SRH_CHECK(sr_mesh_create(device.device(), vertices.data(), static_cast<std::uint32_t>(vertices.size()), indices.data(),
+                             static_cast<std::uint32_t>(indices.size()), &m));
+    return StaticMesh{device.device(), m, static_cast<std::uint32_t>(indices.size())};
+}
+
+struct Texture {               // plain struct with manual destroy, as in src/texture.hpp:9-24
+    std::uint32_t mip_levels{};
+    sr_texture image{};
+};
+
+[[nodiscard]] inline Texture create_texture(vkh::GPUDevice& device, void* data, int tex_width, int tex_height)
+{
+    Texture t;
+    SRH_CHECK(sr_texture_create_rgba8_srgb(device.device(), data, tex_width, tex_height, nullptr, &t.image));
+    t.mip_levels = static_cast<std::uint32_t>(sr_texture_mip_levels(t.image));
+    return t;
+}
+
+inline void destroy_texture(vkh::GPUDevice& device, Texture& texture)
+{
+    sr_texture_destroy(device.device(), texture.image);
+    texture.image = nullptr;
+}
+
+// Stands for the swap-chain image plus the multisampled colour and depth attachments
+// (src/main.cpp:723-738) and for draw_frame's submit (src/main.cpp:1006-1076).
+class RenderTarget {
+public:
+    RenderTarget(vkh::GPUDevice& device, int width, int height, int samples = 1, std::uint32_t n_views = 1)
+        : device_(device.device()), width_(width), height_(height)
+    {
+        SRH_CHECK(sr_target_create(device_, width, height, samples, n_views, nullptr, &target_));
+    }
+    ~RenderTarget() { sr_target_destroy(device_, target_); }
+    RenderTarget(const RenderTarget&) = delete;
+    RenderTarget& operator=(const RenderTarget&) = delete;
+
+    // albedo, normal, metallic, roughness: the descriptor bindings 1-4 of src/main.cpp:461-516
+    void draw(const StaticMesh& mesh, const UniformBufferObject& ubo, const Texture& albedo, const Texture& normal,
+              const Texture& metallic, const Texture& roughness)
+    {
+        const sr_texture tex[4] = {albedo.image, normal.image, metallic.image, roughness.image};
+        SRH_CHECK(sr_draw(device_, target_, mesh.handle(), &ubo, 1, sizeof(UniformBufferObject), tex));
+    }
+    [[nodiscard]] std::vector<std::uint8_t> read_color_bgra()
+    {
+        std::vector<std::uint8_t> out(static_cast<std::size_t>(width_) * height_ * 4);
+        SRH_CHECK(sr_target_readback(device_, target_, SR_READ_COLOR_BGRA8, 0, out.data(), out.size()));
+        return out;
+    }
+    [[nodiscard]] sr_draw_stats stats()
+    {
+        sr_draw_stats s{};
+        SRH_CHECK(sr_draw_get_stats(device_, target_, &s));
+        return s;
+    }
+
+private:
+    sr_device device_;
+    sr_target target_ = nullptr;
+    int width_, height_;
+};
