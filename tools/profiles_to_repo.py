@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Copies the summaries of gpurun_out/profile_round into profiles/ (tracked) and derives traffic.json:
+HBM bytes per launch of each kernel = (2 * FETCH_SIZE + WRITE_SIZE) KiB, the factor 2 being the gfx950
+correction for FETCH_SIZE (it reports half the bytes of a coalesced read; checked here on the vertex
+kernel, whose read volume is known exactly: 12 bytes per vertex)."""
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = "gpurun_out/profile_round"
+os.makedirs("profiles", exist_ok=True)
+stats = glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True)[0]
+shutil.copy(stats, f"profiles/{tag}_c3_kernel_stats.csv")
+line = [l for l in open(root + "/trace.log") if l.startswith("{")][-1]
+open(f"profiles/{tag}_c3_bench_under_rocprof.json", "w").write(line)
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sr::", "").split("<")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+fetch, write = per_kernel(root + "/fetch", "FETCH_SIZE"), per_kernel(root + "/write", "WRITE_SIZE")
+names = {"begin_pass_kernel": "clear", "vertex_kernel": "vertex", "setup_kernel": "setup", "bin_kernel": "bin", "scan_kernel": "scan",
+         "fill_kernel": "fill", "raster_kernel": "raster", "fragment_kernel": "fragment"}
+traffic, detail = {}, {}
+for k, short in names.items():
+    if k in fetch or k in write:
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        traffic[short] = int((2 * f + w) * 1024)
+        detail[short] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "hbm_bytes": traffic[short]}
+json.dump({"c3_4k_10Mtri": traffic}, open("profiles/traffic.json", "w"), indent=1)
+json.dump({"workload": "c3_4k_10Mtri", "note": "per launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB", "kernels": detail},
+          open(f"profiles/{tag}_c3_hbm_traffic.json", "w"), indent=1)
+print(open(f"profiles/{tag}_c3_kernel_stats.csv").read()[:1800])
+print(json.dumps(detail, indent=1))
