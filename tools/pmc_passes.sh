@@ -4,7 +4,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 run() { # name counters...
   name=$1; shift
@@ -12,6 +12,6 @@ run() { # name counters...
 }
 run sq_a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU &&
 run sq_b SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS &&
-run tcc_rd FETCH_SIZE TCC_HIT_sum &&
-run tcc_wr WRITE_SIZE TCC_MISS_sum TCC_EA0_ATOMIC_sum &&
+run sq_c SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 &&
+run grbm GRBM_GUI_ACTIVE GRBM_COUNT &&
 echo pmc_done

@@ -870,6 +870,23 @@ struct FragParams {
     uint32_t view0;            // first view of this pass inside the target
 };
 
+// window-space position and 1/w of a vertex of a visible triangle (so w > 0), for interpolation only
+__device__ inline ScreenVertex shading_vertex(const ViewXform& vx, float px, float py, float pz, int W, int H)
+{
+#pragma clang fp contract(fast)
+    float wp[4], clip[4];
+    mat4_mul_vec4(vx.model, px, py, pz, 1.0f, wp);
+    mat4_mul_vec4(vx.pv, wp[0], wp[1], wp[2], 1.0f, clip);
+    ScreenVertex sv;
+    const float rw = frcp(clip[3]);
+    const float hw = (float)W * 0.5f, hh = (float)H * 0.5f;
+    sv.X = (int32_t)rintf((clip[0] * rw * hw + hw) * (float)kSubpix);
+    sv.Y = (int32_t)rintf((clip[1] * rw * (-hh) + hh) * (float)kSubpix);
+    sv.z = 0.0f;
+    sv.rw = rw;
+    return sv;
+}
+
 // shades triangle `tri` at pixel (x,y): packed B,G,R,A.  Barycentrics are evaluated in float relative
 // to vertex 0 (exact for triangles up to a few hundred pixels, 2^-24 relative otherwise); the values
 // at the other pixels of the 2x2 quad follow from their screen-space gradients.
@@ -880,7 +897,13 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     const float4 a0 = p.verts[2 * (size_t)i0], b0 = p.verts[2 * (size_t)i0 + 1];
     const float4 a1 = p.verts[2 * (size_t)i1], b1 = p.verts[2 * (size_t)i1 + 1];
     const float4 a2 = p.verts[2 * (size_t)i2], b2 = p.verts[2 * (size_t)i2 + 1];
-    const ScreenVertex v0 = load_screen_vertex(p.screen, sv_base + i0), v1 = load_screen_vertex(p.screen, sv_base + i1), v2 = load_screen_vertex(p.screen, sv_base + i2);
+    // window-space vertices are recomputed from the positions just loaded instead of gathered from the
+    // vertex stage's planes: six divergent loads cost the CU's address/cache path far more than
+    // ~45 arithmetic instructions per vertex.  (Reciprocal instead of division: at worst a vertex lands
+    // on the neighbouring 1/256-pixel position, which moves no colour by an 8-bit step.)
+    const ScreenVertex v0 = shading_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H);
+    const ScreenVertex v1 = shading_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H);
+    const ScreenVertex v2 = shading_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H);
     // edge vectors relative to v0, 1/256 pixel; weights: l1 = cross(p - v0, e2) / A', l2 = cross(e1, p - v0) / A'
     const float e1x = (float)(v1.X - v0.X), e1y = (float)(v1.Y - v0.Y);
     const float e2x = (float)(v2.X - v0.X), e2y = (float)(v2.Y - v0.Y);
