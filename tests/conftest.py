@@ -20,9 +20,20 @@ def oracle():
     return o
 
 
+EMULATED = os.environ.get("SR_TEST_EMULATED") == "1"
+
+
 @pytest.fixture(scope="session")
 def sr():
     import softraster
+    if EMULATED:
+        # Set only by tests/test_emulated_kernels.py for its child process: the kernel sources compiled
+        # for the host (tests/emu) stand in for the GPU library, so that the gpu-marked tests double as
+        # a bounds and synchronisation check that needs no GPU.  Never set on a GPU box.
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+        import build_emu
+        softraster.LIB_PATH = build_emu.build()
+        print(f"\n*** SR_TEST_EMULATED=1: kernels run on the CPU through {softraster.LIB_PATH} ***")
     return softraster
 
 

@@ -1,0 +1,61 @@
+"""TEST INFRASTRUCTURE ONLY: builds the rasteriser's kernel and API sources for the HOST against the
+stand-in HIP header of this directory -> tests/emu/_build/libsoftraster_emu.so.
+
+The product sources are used as they are; the only rewriting is the triple-chevron launch syntax,
+which a host C++ compiler cannot parse:   kernel<<<grid, block, lds, stream>>>(args)
+becomes                                   ::hipemu::Launch(grid, block, lds, stream).go("kernel", kernel, args)
+The rewritten copies live in _build/ (git-ignored) and are regenerated whenever a source changes.
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "vulkan-renderer_amd", "csrc")
+BUILD = os.path.join(HERE, "_build")
+LIB = os.path.join(BUILD, "libsoftraster_emu.so")
+SOURCES = ("sr_kernels.hip", "sr_api.hip")
+HEADERS = ("sr_device.h", "sr_launch.h")
+
+_LAUNCH = re.compile(r"([A-Za-z_]\w*(?:<[^<>;()]*>)?)\s*<<<(.*?)>>>\s*\(")
+
+
+def translate(text: str) -> str:
+    out, n = _LAUNCH.subn(lambda m: f'::hipemu::Launch({m.group(2)}).go("{m.group(1)}", {m.group(1)}, ', text)
+    if "<<<" in out:
+        raise RuntimeError("a kernel launch was not recognised by the rewriter")
+    return out
+
+
+def newest(paths) -> float:
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force: bool = False, opt: str = "-O1") -> str:
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps += [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "hipemu.cpp"), os.path.abspath(__file__),
+             os.path.join(ROOT, "include", "softraster.h")]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest(deps):
+        return LIB
+    os.makedirs(BUILD, exist_ok=True)
+    units = []
+    for f in SOURCES:
+        with open(os.path.join(CSRC, f)) as fh:
+            text = translate(fh.read())
+        dst = os.path.join(BUILD, f.replace(".hip", "_emu.cpp"))
+        with open(dst, "w") as fh:
+            fh.write(f'#line 1 "{os.path.join(CSRC, f)}"\n' + text)
+        units.append(dst)
+    cmd = ["g++", "-std=c++17", opt, "-g", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-Wl,-Bsymbolic", "-Wno-unknown-pragmas", "-U_FORTIFY_SOURCE",
+           "-I", HERE, "-I", CSRC, *units, os.path.join(HERE, "hipemu.cpp"), "-o", LIB]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -173,6 +173,8 @@ def test_cpp_host_app_matches_python_host(sr, device, tmp_path):
     its frame equals the Python host's up to the sphere's last-bit vertex differences."""
     import os
     import subprocess
+    if os.environ.get("SR_TEST_EMULATED") == "1":
+        pytest.skip("the C++ application links the GPU library; not part of the CPU emulation run")
     app = os.path.join(os.path.dirname(sr.LIB_PATH), "headless_app")
     assert os.path.exists(app), "build it with __graft_entry__.build()"
     out = tmp_path / "frame.ppm"
@@ -191,6 +193,9 @@ def test_cpp_host_app_matches_python_host(sr, device, tmp_path):
 
 def test_colour_bound_to_caller_memory(sr, oracle, device):
     """sr_target_bind_color: the frame lands in a torch tensor (what the sort-first composite hands to RCCL)."""
+    import os
+    if os.environ.get("SR_TEST_EMULATED") == "1":
+        pytest.skip("needs a torch tensor in GPU memory; not part of the CPU emulation run")
     import torch
     from softraster import distributed as d
     verts, idx = sr.scene.uv_sphere(32, 24)

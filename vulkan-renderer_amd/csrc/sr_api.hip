@@ -313,7 +313,13 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (!out) return fail(SR_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return fail(SR_ERR_NO_DEVICE, "no HIP device visible"); }
+    const hipError_t count_err = hipGetDeviceCount(&count);
+    if (count_err != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        /* a GPU left faulted by an earlier process shows up here as an error, not as zero devices */
+        return fail(SR_ERR_NO_DEVICE, std::string("no HIP device visible (hipGetDeviceCount: ") +
+                                          hipGetErrorString(count_err) + ", count " + std::to_string(count) + ")");
+    }
     if (hip_ordinal < 0 || hip_ordinal >= count) return fail(SR_ERR_NO_DEVICE, "HIP ordinal out of range");
     hipDeviceProp_t prop;
     SR_HIP(hipGetDeviceProperties(&prop, hip_ordinal));
