@@ -4,6 +4,10 @@
 # touches the GPU after a failing step (a failing step may be a GPU fault).  On failure the first
 # failing test's report is printed, not the last lines of the log.
 cd /root/repo && python -c "import __graft_entry__ as g; g.build()" || exit 1
+# Gate: the same sources must first pass the gpu suite on the CPU execution harness, where an
+# out-of-range access is a test failure instead of a dead GPU.
+SR_TEST_EMULATED=1 timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > /tmp/emu_gate.log 2>&1 || { echo "emulated run failed: not going to the GPU"; tail -30 /tmp/emu_gate.log; exit 1; }
+tail -1 /tmp/emu_gate.log
 (timeout 1500 /usr/local/graft/bin/gpurun --timeout 600 -- "
 report() { echo \"step \$1 failed\"; grep -n -m1 -A40 '^=* FAILURES\|^E  ' gpurun_out/test.log; tail -5 gpurun_out/\$2; exit 1; }
 timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/test.log 2>&1 || report tests test.log

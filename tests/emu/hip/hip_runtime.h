@@ -105,6 +105,7 @@ struct Lane {                // what a work-item knows about itself
     uint32_t lane;           // flat & 63
 };
 extern Lane* cur;            // the work-item that is running now
+extern bool g_fuzz_ulp;      // HIPEMU_FUZZ_ULP=1
 extern uint3 g_block_idx;
 extern dim3 g_block_dim, g_grid_dim;
 
@@ -181,10 +182,22 @@ static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) { const uin
 static inline uint32_t hipemu_mbcnt_hi(uint32_t mask, uint32_t base) { const uint32_t l = ::hipemu::cur->lane; return base + (uint32_t)__builtin_popcount(mask & (l <= 32 ? 0u : ((1u << (l - 32)) - 1u))); }
 #define __builtin_amdgcn_mbcnt_lo(m, b) hipemu_mbcnt_lo((m), (b))
 #define __builtin_amdgcn_mbcnt_hi(m, b) hipemu_mbcnt_hi((m), (b))
-#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-#define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
-#define __builtin_amdgcn_exp2f(x) exp2f(x)
-#define __builtin_amdgcn_logf(x) log2f(x)
+// The hardware's rcp/rsq/exp2/log are 1-ulp approximations.  With HIPEMU_FUZZ_ULP=1 every result is
+// moved by -1, 0 or +1 ulp (a fixed pseudo-random function of the result), which shows whether code
+// that uses them tolerates any such rounding, not just the host's.
+static inline float hipemu_approx(float v)
+{
+    if (!::hipemu::g_fuzz_ulp || !std::isfinite(v) || v == 0.0f) return v;
+    uint32_t b; std::memcpy(&b, &v, 4);
+    uint32_t h = b * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    b += (h % 3u) - 1u;
+    std::memcpy(&v, &b, 4);
+    return v;
+}
+#define __builtin_amdgcn_rcpf(x) hipemu_approx(1.0f / (x))
+#define __builtin_amdgcn_rsqf(x) hipemu_approx(1.0f / sqrtf(x))
+#define __builtin_amdgcn_exp2f(x) hipemu_approx(exp2f(x))
+#define __builtin_amdgcn_logf(x) hipemu_approx(log2f(x))
 
 // atomics: lanes never run concurrently here, so plain read-modify-write is exact
 template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = (T)(o + v); return o; }

@@ -15,9 +15,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_gpu_suite_emulated(order, select=None, timeout=900):
-    env = dict(os.environ, SR_TEST_EMULATED="1", HIPEMU_ORDER=order)
-    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"]
+def run_gpu_suite_emulated(order, select=None, timeout=900, what="tests", **extra_env):
+    env = dict(os.environ, SR_TEST_EMULATED="1", HIPEMU_ORDER=order, **extra_env)
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, what), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"]
     if select:
         cmd += ["-k", select]
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
@@ -39,6 +39,14 @@ def test_results_do_not_depend_on_lane_order(order):
     """Same results when the lanes of a workgroup run in another order between synchronisation
     points: a missing barrier or an order-dependent reservation shows up as a parity failure."""
     run_gpu_suite_emulated(order, select="soup or huge or golden or split or multi_view or errors or trailing")
+
+
+def test_full_size_frame_on_emulated_kernels():
+    """The 10 M-triangle 3840x2160 frame of the headline benchmark, executed on the CPU (about a
+    minute), with every result of the hardware's approximate reciprocal / rsqrt / exp2 / log2 moved
+    by up to one ulp: windows against the oracle plus the whole-frame properties."""
+    run_gpu_suite_emulated("forward", what=os.path.join("tests", "test_gpu_zz_full_size.py"), timeout=1500,
+                           SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1")
 
 
 def test_out_of_range_access_is_reported(tmp_path):
