@@ -105,7 +105,7 @@ struct Lane {                // what a work-item knows about itself
     uint32_t lane;           // flat & 63
 };
 extern Lane* cur;            // the work-item that is running now
-extern bool g_fuzz_ulp;      // HIPEMU_FUZZ_ULP=1
+extern int g_fuzz_ulp;       // HIPEMU_FUZZ_ULP=n: results of rcp/rsq/exp2/log move by up to n ulp
 extern uint3 g_block_idx;
 extern dim3 g_block_dim, g_grid_dim;
 
@@ -182,15 +182,16 @@ static inline uint32_t hipemu_mbcnt_lo(uint32_t mask, uint32_t base) { const uin
 static inline uint32_t hipemu_mbcnt_hi(uint32_t mask, uint32_t base) { const uint32_t l = ::hipemu::cur->lane; return base + (uint32_t)__builtin_popcount(mask & (l <= 32 ? 0u : ((1u << (l - 32)) - 1u))); }
 #define __builtin_amdgcn_mbcnt_lo(m, b) hipemu_mbcnt_lo((m), (b))
 #define __builtin_amdgcn_mbcnt_hi(m, b) hipemu_mbcnt_hi((m), (b))
-// The hardware's rcp/rsq/exp2/log are 1-ulp approximations.  With HIPEMU_FUZZ_ULP=1 every result is
-// moved by -1, 0 or +1 ulp (a fixed pseudo-random function of the result), which shows whether code
-// that uses them tolerates any such rounding, not just the host's.
+// The hardware's rcp/rsq/exp2/log are 1-ulp approximations.  With HIPEMU_FUZZ_ULP=n every result is
+// moved by -n..+n ulp (a fixed pseudo-random function of the result), which shows whether code that
+// uses them tolerates any such rounding, not just the host's.
 static inline float hipemu_approx(float v)
 {
     if (!::hipemu::g_fuzz_ulp || !std::isfinite(v) || v == 0.0f) return v;
     uint32_t b; std::memcpy(&b, &v, 4);
     uint32_t h = b * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-    b += (h % 3u) - 1u;
+    const uint32_t span = (uint32_t)::hipemu::g_fuzz_ulp;   // 1: -1..+1 ulp, 2: -2..+2 ulp, ...
+    b += (h % (2u * span + 1u)) - span;
     std::memcpy(&v, &b, 4);
     return v;
 }

@@ -56,7 +56,7 @@ hipemu_switch:
 namespace hipemu {
 
 Lane* cur = nullptr;
-bool g_fuzz_ulp = [] { const char* e = std::getenv("HIPEMU_FUZZ_ULP"); return e && e[0] == '1'; }();
+int g_fuzz_ulp = [] { const char* e = std::getenv("HIPEMU_FUZZ_ULP"); return e ? std::max(0, std::atoi(e)) : 0; }();
 uint3 g_block_idx = {0, 0, 0};
 dim3 g_block_dim, g_grid_dim;
 
