@@ -219,7 +219,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "width": W, "height": H, "triangles": T, "vertices": V, "samples": 1,
-                       "views_per_gpu": 1, "sharding": "by view (no collective)" if world > 1 else "single GPU"},
+                       "views_per_gpu": 1, "sharding": "by view (no collective)" if world > 1 else "single GPU",
+                       "pipeline_variant": os.environ.get("SR_VARIANT", "") or "default"},
             "frames_per_s": round(frames_per_s, 2),
             "gpixels_shaded_per_s": round(shaded_total * args.steps / elapsed / 1e9, 4),
             "counters": {"V": V, "T": T, "R": R, "F": F, "P": P, "Pv": Pv, "S": 1, "binned": surv, "direct": stats["triangles_direct"]},

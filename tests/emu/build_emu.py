@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "vulkan-renderer_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "libsoftraster_emu.so")
 SOURCES = ("sr_kernels.hip", "sr_api.hip")
-HEADERS = ("sr_device.h", "sr_launch.h")
+HEADERS = ("sr_device.h", "sr_launch.h", "sr_setup_body.inc")
 
 _LAUNCH = re.compile(r"([A-Za-z_]\w*(?:<[^<>;()]*>)?)\s*<<<(.*?)>>>\s*\(")
 

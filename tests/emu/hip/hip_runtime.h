@@ -175,6 +175,7 @@ static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 

@@ -41,6 +41,14 @@ def test_results_do_not_depend_on_lane_order(order):
     run_gpu_suite_emulated(order, select="soup or huge or golden or split or multi_view or errors or trailing")
 
 
+@pytest.mark.parametrize("variant", ["fused_geometry", "dirty_blocks"])
+def test_pipeline_variants_give_the_same_frames(variant):
+    """The switchable pipeline variants (environment variable SR_VARIANT, see sr_api.hip) must pass the
+    same parity suite as the default pipeline."""
+    run_gpu_suite_emulated("forward", SR_VARIANT=variant)
+    run_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full", SR_VARIANT=variant)
+
+
 def test_full_size_frame_on_emulated_kernels():
     """The 10 M-triangle 3840x2160 frame of the headline benchmark, executed on the CPU (about a
     minute), with every result of the hardware's approximate reciprocal / rsqrt / exp2 / log2 moved

@@ -107,6 +107,40 @@ def test_empty_mesh_and_offscreen_mesh(sr, oracle, device):
     assert (got["tri"] == sr.NO_TRIANGLE).all()
 
 
+@pytest.mark.parametrize("samples", [1, 4])
+def test_target_is_reused_across_different_draws(sr, oracle, device, samples):
+    """One target, a sequence of unrelated draws: nothing of an earlier frame may survive into a later
+    one.  Sphere in two views -> nothing in view 0 only -> a small soup in both views -> the sphere again
+    from another camera in view 0 only; every frame is checked against the oracle."""
+    W, H = 200, 120
+    sphere = sr.scene.uv_sphere(24, 16)
+    soup = util.random_soup(40, 5, size=0.5)
+    nothing = (np.zeros((0, 8), np.float32), np.zeros(0, np.uint32))
+    images = sr.scene.material_textures(32)
+    cams = sr.scene.orbit_ubos(3, W, H)
+    tex = [sr.create_texture(device, im) for im in images]
+    meshes = {k: sr.create_mesh_from_data(device, *v) for k, v in (("sphere", sphere), ("soup", soup), ("nothing", nothing))}
+    data = {"sphere": sphere, "soup": soup, "nothing": nothing}
+    tgt = sr.RenderTarget(device, W, H, samples=samples, n_views=2)
+    try:
+        expected = [None, None]   # what each view of the target must hold now
+        for what, ubos in (("sphere", cams[:2]), ("nothing", cams[:1]), ("soup", cams[1:3]), ("sphere", cams[2:3])):
+            sr.draw(device, tgt, meshes[what], ubos, tex)
+            for v in range(len(ubos)):
+                expected[v] = oracle.draw(ubos[v], data[what][0], data[what][1], images, W, H, samples)
+            for v in range(2):
+                got = {"tri": tgt.read_triangle_ids(v), "depth": tgt.read_depth(v), "bgra": tgt.read_color(v)}
+                util.assert_visibility_equal(got, expected[v])
+                frac, worst = util.color_match_fraction(got["bgra"], expected[v]["bgra"])
+                assert frac >= 0.999, (what, v, frac, worst)
+    finally:
+        tgt.destroy()
+        for m in meshes.values():
+            m.destroy()
+        for t in tex:
+            t.destroy()
+
+
 def test_multi_view_batch_matches_single_views(sr, oracle, device):
     """BASELINE config 2 in small: a batch of orbit cameras drawn by one call."""
     verts, idx = sr.scene.uv_sphere(32, 32)

@@ -36,6 +36,10 @@ def fingerprints(asm: str) -> dict:
     for m in body.finditer(asm):
         name, text = m.group(1), m.group(2)
         code = "\n".join(l.split(";")[0].rstrip() for l in text.splitlines() if l.strip() and not l.lstrip().startswith(";"))
+        code = re.sub(r"\.LBB\d+_(\d+)", r".LBB_\1", code)   # local labels carry the function's ordinal in the file
+        # instructions and labels only: directives (kernel descriptor, section names, kernarg size) name the symbol
+        code = "\n".join(l for l in code.splitlines() if not l.lstrip().startswith(".") or l.lstrip().startswith(".LBB_"))
+        code = re.sub(r"_Z\w+", "SYM", code)
         out[name] = {"sha": hashlib.sha256(code.encode()).hexdigest()[:16], "lines": code.count("\n") + 1}
     for m in re.finditer(r"\.amdhsa_kernel (\w+)\n(.*?)\.end_amdhsa_kernel", asm, re.S):
         k = out.get(m.group(1))
@@ -73,12 +77,19 @@ def main():
         changed = [k for k in cur if k in ref and cur[k]["sha"] != ref[k]["sha"]]
         new = [k for k in cur if k not in ref]
         gone = [k for k in ref if k not in cur]
+        # a kernel that only changed its name (say, a template parameter was added) but not its code
+        ref_by_sha = {ref[k]["sha"]: k for k in gone}
+        renamed = [(k, ref_by_sha[cur[k]["sha"]]) for k in new if cur[k]["sha"] in ref_by_sha]
+        for k, was in renamed:
+            print(f"RENAMED  {k}\n         same code as recorded {was}")
+            new.remove(k)
+            gone.remove(was)
         for tag, lst in (("CHANGED", changed), ("NEW", new), ("REMOVED", gone)):
             for k in lst:
                 v = cur.get(k) or ref[k]
                 print(f"{tag:8s} {k}  vgprs={v.get('vgprs')} lds={v.get('lds')} scratch={v.get('scratch')}")
-        print(f"{len(cur) - len(changed) - len(new)} of {len(cur)} kernels are the recorded machine code")
-        sys.exit(1 if (changed or new or gone) else 0)
+        print(f"{len(cur) - len(changed) - len(new)} of {len(cur)} kernels are the recorded machine code; {len(new)} new, {len(changed)} changed, {len(gone)} removed")
+        sys.exit(1 if (changed or gone) else 0)
     if not a.save and not a.compare:
         for k, v in sorted(fp.items()):
             print(f"{v['sha']} {v['lines']:6d} lines vgprs={v.get('vgprs')} sgprs={v.get('sgprs')} lds={v.get('lds')} scratch={v.get('scratch')}  {pretty[k]}")

@@ -49,6 +49,30 @@ struct DeviceBuffer {
 constexpr int kNumStageEvents = 9;   // start, clear, vertex, setup, bin, scan, fill, raster, fragment
 constexpr int kCountersPerPass = 8;  // total refs, dropped refs, unprojectable triangles, binned triangles, micro-triangles, spare
 
+// Pipeline variants that can be switched on per device with the environment variable SR_VARIANT
+// (comma-separated names).  They produce the same frames as the default pipeline (the parity tests
+// run with each of them); they exist so that alternatives can be timed against each other on the GPU.
+enum : unsigned {
+    kVariantFusedGeometry = 1u << 0,   // "fused_geometry": triangle set-up transforms the vertices itself, no vertex pass
+    kVariantDirtyBlocks = 1u << 1,     // "dirty_blocks": per-block dirty map; only written blocks are cleared and read back by shading
+                                       //                 (the marking lives in the fused set-up kernel, so this implies fused_geometry)
+};
+
+unsigned parse_variants(const char* text)
+{
+    unsigned v = 0;
+    const std::string s = text ? text : "";
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        const size_t end = std::min(s.find(',', pos), s.size());
+        const std::string name = s.substr(pos, end - pos);
+        if (name == "fused_geometry") v |= kVariantFusedGeometry;
+        if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
+        pos = end + 1;
+    }
+    return v;
+}
+
 }  // namespace
 
 struct sr_device_t {
@@ -66,6 +90,7 @@ struct sr_device_t {
     uint64_t ref_capacity = 0;
     size_t scratch_budget = (size_t)16 << 30;
     int tile_log2_override = 0;
+    unsigned variants = 0;       // kVariant* bits, from SR_VARIANT
     bool profiling = false;
     std::vector<hipEvent_t> events;   // kNumStageEvents per pass of the last profiled draw
     size_t events_used = 0;
@@ -73,6 +98,7 @@ struct sr_device_t {
 
 struct sr_mesh_t {
     void* d_aos = nullptr;
+    void* d_pos4 = nullptr;      // packed (x, y, z, 1) positions; only with kVariantFusedGeometry
     float *px = nullptr, *py = nullptr, *pz = nullptr;
     uint32_t* d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
@@ -90,6 +116,7 @@ struct sr_target_t {
     FrameGeom g{};
     uint32_t n_views = 0;
     uint64_t* d_vis = nullptr;
+    DirtyMap dirty{nullptr, 0, 0};   // kVariantDirtyBlocks: flags for all views of the target
     uint32_t* d_color_own = nullptr;
     uint32_t* d_color = nullptr;
     // the last draw, kept so that it can be re-issued if the reference list was too small
@@ -236,25 +263,32 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         const ViewXform* d_views = (const ViewXform*)dev->views.ptr + v0;
         hipEvent_t* ev = dev->profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
         if (ev) SR_HIP(hipEventRecord(ev[0], st));
-        launch_begin_pass(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples, b.count_small, zero_words * 4,
-                          sg.d, dev->views.ptr, pass == 0 ? (size_t)n_views * sizeof(ViewXform) : 0);
+        // the dirty map needs the set-up kernel that marks it: meshes created without the packed positions fall back to the full clear
+        const bool fused = (dev->variants & kVariantFusedGeometry) && m->d_pos4;
+        const DirtyMap dirty = fused && tg->dirty.flags ? tg->dirty : DirtyMap{nullptr, 0, 0};
+        if (dirty.flags)
+            launch_begin_pass_dirty(st, tg->d_vis, g, v0, nv, dirty, b.count_small, zero_words * 4,
+                                    sg.d, dev->views.ptr, pass == 0 ? (size_t)n_views * sizeof(ViewXform) : 0);
+        else
+            launch_begin_pass(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples, b.count_small, zero_words * 4,
+                              sg.d, dev->views.ptr, pass == 0 ? (size_t)n_views * sizeof(ViewXform) : 0);
         if (pass == 0) { SR_HIP(hipEventRecord(sg.ev, st)); sg.in_flight = true; }
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
-        launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
+        if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr);
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         launch_scan(st, b, nv * n_tiles, nv, (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass);
         if (ev) SR_HIP(hipEventRecord(ev[5], st));
         launch_fill(st, g, b, m->n_tris, nv);
         if (ev) SR_HIP(hipEventRecord(ev[6], st));
-        launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv);
+        launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty);
         if (ev) SR_HIP(hipEventRecord(ev[7], st));
         FragLaunch f{};
         f.idx = m->d_idx; f.verts_aos = m->d_aos; f.screen = sp; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
-        f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv;
+        f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv; f.dirty = dirty;
         launch_fragment(st, f);
         if (ev) SR_HIP(hipEventRecord(ev[8], st));
     }
@@ -339,6 +373,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     SR_HIP(hipMemcpy(dev->d_thresh, thr, sizeof thr, hipMemcpyHostToDevice));
     if (const char* e = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(e);
     if (const char* e = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 30;
+    dev->variants = parse_variants(std::getenv("SR_VARIANT"));
     *out = dev;
     return SR_OK;
 }
@@ -382,11 +417,13 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
     hipError_t e = hipMalloc(&m->d_aos, nv * 32);
     if (e == hipSuccess) e = hipMalloc((void**)&m->px, nv * 12);
     if (e == hipSuccess) e = hipMalloc((void**)&m->d_idx, ni * 4);
-    if (e != hipSuccess) { (void)hipFree(m->d_aos); (void)hipFree(m->px); (void)hipFree(m->d_idx); delete m; SR_HIP(e); }
+    if (e == hipSuccess && (dev->variants & kVariantFusedGeometry)) e = hipMalloc(&m->d_pos4, nv * 16);
+    if (e != hipSuccess) { (void)hipFree(m->d_aos); (void)hipFree(m->px); (void)hipFree(m->d_idx); (void)hipFree(m->d_pos4); delete m; SR_HIP(e); }
     m->py = m->px + nv; m->pz = m->py + nv;
     if (n_vertices) SR_HIP(hipMemcpyAsync(m->d_aos, vertices, (size_t)n_vertices * 32, hipMemcpyHostToDevice, dev->stream));
     if (n_tris) SR_HIP(hipMemcpyAsync(m->d_idx, indices, (size_t)n_tris * 12, hipMemcpyHostToDevice, dev->stream));
     launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
+    if (m->d_pos4) launch_pack_positions(dev->stream, m->d_aos, n_vertices, m->d_pos4);
     SR_HIP(hipGetLastError());
     SR_HIP(hipStreamSynchronize(dev->stream));   // uploaded on return, like the reference's blocking staging copy
     *out = m;
@@ -397,7 +434,7 @@ int sr_mesh_destroy(sr_device dev, sr_mesh mesh)
 {
     if (!mesh) return SR_OK;
     if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
-    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx);
+    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx); (void)hipFree(mesh->d_pos4);
     delete mesh;
     return SR_OK;
 }
@@ -485,6 +522,19 @@ int sr_target_create(sr_device dev, int width, int height, int samples, uint32_t
     if (e == hipSuccess) e = hipMalloc((void**)&t->d_color_own, px * 4 * n_views);
     if (e != hipSuccess) { (void)hipFree(t->d_vis); delete t; SR_HIP(e); }
     t->d_color = t->d_color_own;
+    if (dev->variants & kVariantDirtyBlocks) {
+        // the map's invariant -- an unmarked block holds only the clear value -- starts with one full clear
+        t->dirty.nbx = (g.rw + (1 << kDirtyLog2W) - 1) >> kDirtyLog2W;
+        t->dirty.nby = (g.rh + (1 << kDirtyLog2H) - 1) >> kDirtyLog2H;
+        const size_t flag_bytes = (size_t)n_views * t->dirty.nbx * t->dirty.nby * 4;
+        e = hipMalloc((void**)&t->dirty.flags, flag_bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(t->dirty.flags, 0, flag_bytes, dev->stream);
+        if (e == hipSuccess) {
+            launch_begin_pass(dev->stream, t->d_vis, px * samples * n_views, nullptr, 0, nullptr, nullptr, 0);
+            e = hipStreamSynchronize(dev->stream);
+        }
+        if (e != hipSuccess) { (void)hipFree(t->d_vis); (void)hipFree(t->d_color_own); (void)hipFree(t->dirty.flags); delete t; SR_HIP(e); }
+    }
     *out = t;
     return SR_OK;
 }
@@ -493,7 +543,7 @@ int sr_target_destroy(sr_device dev, sr_target target)
 {
     if (!target) return SR_OK;
     if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
-    (void)hipFree(target->d_vis); (void)hipFree(target->d_color_own);
+    (void)hipFree(target->d_vis); (void)hipFree(target->d_color_own); (void)hipFree(target->dirty.flags);
     if (target->h_counters) (void)hipHostFree(target->h_counters);
     delete target;
     return SR_OK;

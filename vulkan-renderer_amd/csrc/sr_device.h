@@ -218,4 +218,19 @@ struct BinBuffers {
     uint32_t* counters;       // [8]: total refs, dropped refs, unprojectable triangles, binned triangles, micro-triangles resolved directly
 };
 
+// Dirty map (pipeline variant "dirty_blocks"): one flag per 32x8-pixel block of every view of a target,
+// set by whatever writes a sample of the block into the visibility buffer.  Blocks whose flag is clear
+// hold nothing but the clear value, so the shading pass need not read them and the next draw need not
+// clear them: the start of a draw clears the marked blocks of the views it draws and takes their flags back.
+constexpr int kDirtyLog2W = 5, kDirtyLog2H = 3;   // 32 x 8 pixels: the shading pass's workgroup shape
+struct DirtyMap {
+    uint32_t* flags;   // [views of the target][nby][nbx]; null when the variant is off
+    int nbx, nby;
+};
+// lx, ly: pixel position relative to the stored rectangle; view: index inside the target
+__device__ inline void mark_dirty(const DirtyMap& d, uint32_t view, int lx, int ly)
+{
+    d.flags[((size_t)view * d.nby + (ly >> kDirtyLog2H)) * d.nbx + (lx >> kDirtyLog2W)] = 1u;
+}
+
 }  // namespace sr

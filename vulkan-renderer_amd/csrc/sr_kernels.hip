@@ -20,6 +20,15 @@ __global__ __launch_bounds__(256) void split_positions_kernel(const float4* __re
     px[i] = a.x; py[i] = a.y; pz[i] = a.z;
 }
 
+// packed 16-byte positions (x, y, z, 1) for the set-up variant that transforms vertices itself
+__global__ __launch_bounds__(256) void pack_positions_kernel(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ pos4)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = aos[2 * (size_t)i];
+    pos4[i] = make_float4(a.x, a.y, a.z, 1.0f);
+}
+
 // =================================================================================================
 // stage 0: start of a pass.  Clears the visibility buffer (depth 1.0, no triangle; 16 bytes per lane,
 // grid-stride), zeroes the binning counters, and on the first pass of a draw pulls the per-view
@@ -37,6 +46,35 @@ __global__ __launch_bounds__(256) void begin_pass_kernel(ulonglong2* __restrict_
     for (size_t i = gtid; i < n_zero4; i += gstride) zero4[i] = make_uint4(0u, 0u, 0u, 0u);
     const ulonglong2 c = make_ulonglong2(kVisClear, kVisClear);
     for (size_t i = gtid; i < n2; i += gstride) vis2[i] = c;
+}
+
+// Start of a pass with a dirty map: instead of clearing the whole visibility buffer, clear only the
+// 32x8-pixel blocks that were written into since they were last cleared, and take their flags back.
+// One workgroup clears one block per turn: 256 lanes = 32 x 8 pixels, rows of 256 contiguous bytes at
+// one sample per pixel.  vis: the target's whole buffer; views [view0, view0 + n_views) are handled.
+__global__ __launch_bounds__(256) void begin_pass_dirty_kernel(unsigned long long* __restrict__ vis, int rw, int rh, int S, uint32_t view0, uint32_t n_views,
+                                                               DirtyMap dirty, uint4* __restrict__ zero4, size_t n_zero4,
+                                                               const uint4* __restrict__ views_src, uint4* __restrict__ views_dst, uint32_t n_views4)
+{
+    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x, gstride = (size_t)gridDim.x * 256u;
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < n_views4; i += 256u) views_dst[i] = views_src[i];
+    for (size_t i = gtid; i < n_zero4; i += gstride) zero4[i] = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t per_view = (uint32_t)(dirty.nbx * dirty.nby), n_blocks = per_view * n_views;
+    uint32_t* flags = dirty.flags + (size_t)view0 * per_view;
+    const int px = (int)(threadIdx.x & 31u), py = (int)(threadIdx.x >> 5);
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint32_t was = flags[blk];
+        __syncthreads();             // every lane has read the flag before one of them takes it back
+        if (was == 0u) continue;     // uniform over the workgroup
+        if (threadIdx.x == 0) flags[blk] = 0u;
+        const uint32_t view = view0 + blk / per_view, r = blk % per_view;
+        const int x = (int)(r % (uint32_t)dirty.nbx) * 32 + px, y = (int)(r / (uint32_t)dirty.nbx) * 8 + py;
+        if (x < rw && y < rh) {
+            unsigned long long* cell = vis + (((size_t)view * rh + y) * rw + x) * S;
+            for (int s = 0; s < S; ++s) cell[s] = kVisClear;
+        }
+    }
 }
 
 // =================================================================================================
@@ -177,99 +215,21 @@ template <int S>
 __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                     FrameGeom g, BinBuffers b, unsigned long long* __restrict__ vis, uint32_t view0)
 {
-    __shared__ uint32_t s_wave[kTrisPerThread * 4];
-    __shared__ uint32_t s_micro[4];
-    const uint32_t view = blockIdx.y;
-    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const uint32_t blk = blockIdx.x;
-    const int2* xy = sp.xy + (size_t)view * sp.n_verts;
-    uint32_t tri[kTrisPerThread], i0[kTrisPerThread], i1[kTrisPerThread], i2[kTrisPerThread];
-    bool in_range[kTrisPerThread];
-#pragma unroll
-    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-        tri[k] = blk * kBlockTris + k * 256u + tid;
-        in_range[k] = tri[k] < n_tris;
-        const uint32_t tt = in_range[k] ? tri[k] : 0u;
-        i0[k] = idx[3 * (size_t)tt]; i1[k] = idx[3 * (size_t)tt + 1]; i2[k] = idx[3 * (size_t)tt + 2];
-    }
-    int2 r0[kTrisPerThread], r1[kTrisPerThread], r2[kTrisPerThread];
-#pragma unroll
-    for (uint32_t k = 0; k < kTrisPerThread; ++k) { r0[k] = xy[i0[k]]; r1[k] = xy[i1[k]]; r2[k] = xy[i2[k]]; }
+#define SR_SETUP_FUSED 0
+#include "sr_setup_body.inc"
+#undef SR_SETUP_FUSED
+}
 
-    uint32_t n_unproj = 0, n_micro = 0;
-    uint32_t micro_cov[kTrisPerThread], micro_box[kTrisPerThread];   // coverage bits; x0 | y0<<14 | npx<<28
-    bool pend[kTrisPerThread];
-#pragma unroll
-    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-        micro_cov[k] = 0; micro_box[k] = 0; pend[k] = false;
-        const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
-        const int64_t area2 = (int64_t)(r1[k].x - r0[k].x) * (int64_t)(r2[k].y - r0[k].y) - (int64_t)(r2[k].x - r0[k].x) * (int64_t)(r1[k].y - r0[k].y);
-        if (in_range[k] && bad > 0 && bad < 3) ++n_unproj;
-        if (in_range[k] && bad == 0 && area2 < 0) {
-            const int mnx = min(r0[k].x, min(r1[k].x, r2[k].x)), mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
-            const int mny = min(r0[k].y, min(r1[k].y, r2[k].y)), mxy = max(r0[k].y, max(r1[k].y, r2[k].y));
-            int x0, x1, y0, y1;
-            pixel_span<S>(mnx, mxx, x0, x1);
-            pixel_span<S>(mny, mxy, y0, y1);
-            x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
-            y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
-            const int npx = x1 - x0 + 1, npy = y1 - y0 + 1;
-            if (npx > 0 && npy > 0) {
-                if (npx * npy <= kMicroPixels && mxx - mnx < 16384 && mxy - mny < 16384) {
-                    micro_cov[k] = micro_coverage<S>(micro_edges(r0[k], r1[k], r2[k]), x0, y0, npx, npy);
-                    micro_box[k] = (uint32_t)x0 | ((uint32_t)y0 << 14) | ((uint32_t)npx << 28);
-                    if (micro_cov[k]) ++n_micro;
-                } else pend[k] = true;
-            }
-        }
-    }
-    // micro-triangles with a covered sample: fetch the three depths (all loads first), then resolve
-    {
-        const float2* zw = sp.zw + (size_t)view * sp.n_verts;
-        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
-        float z0[kTrisPerThread], z1[kTrisPerThread], z2[kTrisPerThread];
-#pragma unroll
-        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-            z0[k] = z1[k] = z2[k] = 0.0f;
-            if (micro_cov[k]) { z0[k] = zw[i0[k]].x; z1[k] = zw[i1[k]].x; z2[k] = zw[i2[k]].x; }
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-            if (!micro_cov[k]) continue;
-            const int32_t A = -((r1[k].x - r0[k].x) * (r2[k].y - r0[k].y) - (r2[k].x - r0[k].x) * (r1[k].y - r0[k].y));
-            micro_resolve<S>(micro_edges(r0[k], r1[k], r2[k]), micro_cov[k], (int)(micro_box[k] & 16383u), (int)((micro_box[k] >> 14) & 16383u),
-                             (int)(micro_box[k] >> 28), z0[k], z1[k], z2[k], 1.0f / (float)A, tri[k], vis_view, g);
-        }
-    }
-    if (n_unproj) atomicAdd(&b.counters[2], n_unproj);   // triangles that would need clipping (rare)
-    // hand the remaining triangles to the binning kernel
-    uint64_t m[kTrisPerThread];
-#pragma unroll
-    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-        m[k] = __ballot(pend[k]);
-        if (lane == 0) s_wave[k * 4u + wave] = (uint32_t)__popcll(m[k]);
-    }
-    {
-        uint32_t w = n_micro;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) w += (uint32_t)__shfl_down((int)w, o);
-        if (lane == 0) s_micro[wave] = w;
-    }
-    __syncthreads();
-    uint32_t run = 0;
-    uint32_t* slice = b.pending + ((size_t)view * b.n_blocks + blk) * kBlockTris;
-#pragma unroll
-    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
-#pragma unroll
-        for (uint32_t w = 0; w < 4; ++w) {
-            if (w == wave && pend[k]) slice[run + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))] = tri[k];
-            run += s_wave[k * 4u + w];
-        }
-    }
-    if (tid == 0) {
-        b.pending_count[(size_t)view * b.n_blocks + blk] = run;
-        b.block_live[(size_t)view * b.n_blocks + blk] = run | ((s_micro[0] + s_micro[1] + s_micro[2] + s_micro[3]) << 16);
-    }
+// Set-up with the vertex stage fused in (see sr_setup_body.inc); pos4: packed positions, views: the
+// transforms of the views of this pass, dirty: optional dirty map (flags == null: not tracked).
+template <int S>
+__global__ __launch_bounds__(256) void geometry_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
+                                                       FrameGeom g, BinBuffers b, unsigned long long* __restrict__ vis, uint32_t view0,
+                                                       const float4* __restrict__ pos4, const ViewXform* __restrict__ views, DirtyMap dirty)
+{
+#define SR_SETUP_FUSED 1
+#include "sr_setup_body.inc"
+#undef SR_SETUP_FUSED
 }
 
 // Binning of the triangles set-up left pending.  Block b takes slice b of the pending list, in a
@@ -561,10 +521,10 @@ __device__ inline void raster_pixel32(const TriSetup& ts, uint32_t tri, int x, i
     }
 }
 
-template <int TL2, int S, int TPB>
+template <int TL2, int S, int TPB, bool DIRTY = false>
 __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                      FrameGeom g, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ refs,
-                                                     uint32_t ref_capacity, unsigned long long* __restrict__ vis, uint32_t view0)
+                                                     uint32_t ref_capacity, unsigned long long* __restrict__ vis, uint32_t view0, DirtyMap dirty)
 {
     constexpr int T = 1 << TL2;
     constexpr int kSmall = 16;   // bounding boxes up to this many pixels are walked by one lane
@@ -685,7 +645,10 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
     for (int i = tid; i < T * T * S; i += TPB) {
         const int s = i % S, p = i / S, lx = p & (T - 1), ly = p >> TL2;
         // merge with what micro-triangles already resolved in HBM; untouched samples cost nothing
-        if (lx < tw && ly < th && tile[i] != kVisClear) atomicMin(&out[((size_t)(py0 - g.ry + ly) * g.rw + (px0 - g.rx + lx)) * S + s], tile[i]);
+        if (lx < tw && ly < th && tile[i] != kVisClear) {
+            atomicMin(&out[((size_t)(py0 - g.ry + ly) * g.rw + (px0 - g.rx + lx)) * S + s], tile[i]);
+            if constexpr (DIRTY) mark_dirty(dirty, view0 + view, px0 - g.rx + lx, py0 - g.ry + ly);
+        }
     }
 }
 
@@ -868,6 +831,7 @@ struct FragParams {
     TexDesc albedo, metallic, roughness;
     ShadeTables tab;
     uint32_t view0;            // first view of this pass inside the target
+    DirtyMap dirty;            // read by fragment_kernel<S, true> only
 };
 
 // window-space position and 1/w of a vertex of a visible triangle (so w > 0), for interpolation only
@@ -954,13 +918,21 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     return B | (G << 8) | (R << 16) | (255u << 24);
 }
 
-template <int S>
+template <int S, bool DIRTY = false>
 __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
 {
     __shared__ float s_dec[256];
     __shared__ float s_thr[256];
     __shared__ uint32_t s_lvl[3 * kMaxMipLevels];
     const uint32_t tid = threadIdx.y * 32u + threadIdx.x;
+    if constexpr (DIRTY) {
+        // the workgroup is one block of the dirty map: nothing was drawn into a clean block
+        if (p.dirty.flags[((size_t)(p.view0 + blockIdx.z) * p.dirty.nby + blockIdx.y) * p.dirty.nbx + blockIdx.x] == 0u) {
+            const int cx = (int)(blockIdx.x * 32u + threadIdx.x), cy = (int)(blockIdx.y * 8u + threadIdx.y);
+            if (cx < p.g.rw && cy < p.g.rh) p.color[((size_t)(p.view0 + blockIdx.z) * p.g.rh + cy) * p.g.rw + cx] = kColorClear;
+            return;
+        }
+    }
     s_dec[tid] = p.tab.decode[tid];
     s_thr[tid] = tid < 255u ? p.tab.thresh[tid] : 3.0e38f;
     if (tid < 3u * kMaxMipLevels) {
@@ -1099,6 +1071,15 @@ void launch_begin_pass(hipStream_t st, uint64_t* vis, size_t n, void* zero16, si
                                               (uint4*)zero16, zero_bytes / 16, (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
 }
 
+void launch_begin_pass_dirty(hipStream_t st, uint64_t* vis, const FrameGeom& g, uint32_t view0, uint32_t n_views, const DirtyMap& dirty,
+                             void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes)
+{
+    const uint32_t n_blocks = (uint32_t)(dirty.nbx * dirty.nby) * n_views;
+    const uint32_t blocks = std::min<uint32_t>(std::max<uint32_t>(n_blocks, 1u), 256u * 16u);
+    begin_pass_dirty_kernel<<<blocks, 256, 0, st>>>((unsigned long long*)vis, g.rw, g.rh, g.samples, view0, n_views, dirty,
+                                                    (uint4*)zero16, zero_bytes / 16, (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
+}
+
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
                    int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out)
 {
@@ -1106,12 +1087,22 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
     vertex_kernel<<<dim3(div_up(n, 256), n_views), 256, 0, st>>>(px, py, pz, n, views, W, H, out, debug_out, (float4*)clip_out);
 }
 
+void launch_pack_positions(hipStream_t st, const void* aos, uint32_t n, void* pos4)
+{
+    if (!n) return;
+    pack_positions_kernel<<<div_up(n, 256), 256, 0, st>>>((const float4*)aos, n, (float4*)pos4);
+}
+
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
-                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between)
+                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between,
+                  const void* pos4, const ViewXform* views, const DirtyMap& dirty)
 {
     if (!n_tris || !n_views) return;
     const dim3 grid(b.n_blocks, n_views);
-    if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
+    if (pos4) {
+        if (g.samples == 1) geometry_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty);
+        else geometry_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty);
+    } else if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
     else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
     if (between) (void)hipEventRecord(between, st);
     if (g.samples == 1) bin_kernel<1><<<grid, 256, 0, st>>>(idx, sp, g, b);
@@ -1129,20 +1120,24 @@ void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32
     fill_kernel<<<dim3(b.n_blocks, n_views), 256, 0, st>>>(g, b);
 }
 
+template <int TL2, int S, int TPB>
+static void launch_raster_config(hipStream_t st, dim3 grid, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
+                                 unsigned long long* v, uint32_t view0, const DirtyMap& dirty)
+{
+    if (dirty.flags) raster_kernel<TL2, S, TPB, true><<<grid, TPB, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0, dirty);
+    else raster_kernel<TL2, S, TPB, false><<<grid, TPB, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0, dirty);
+}
+
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                   uint64_t* vis, uint32_t view0, uint32_t n_views)
+                   uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty)
 {
     if (!n_views) return;
     const dim3 grid((uint32_t)(g.tiles_x * g.tiles_y), n_views);
     unsigned long long* v = (unsigned long long*)vis;
-    if (g.samples == 1 && g.tile_log2 == 6)
-        raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
-    else if (g.samples == 1 && g.tile_log2 == 5)
-        raster_kernel<5, 1, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
-    else if (g.samples == 4 && g.tile_log2 == 5)
-        raster_kernel<5, 4, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
-    else if (g.samples == 4 && g.tile_log2 == 4)
-        raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    if (g.samples == 1 && g.tile_log2 == 6) launch_raster_config<6, 1, 1024>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
+    else if (g.samples == 1 && g.tile_log2 == 5) launch_raster_config<5, 1, 256>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
+    else if (g.samples == 4 && g.tile_log2 == 5) launch_raster_config<5, 4, 1024>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
+    else if (g.samples == 4 && g.tile_log2 == 4) launch_raster_config<4, 4, 256>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
 }
 
 uint32_t setup_block_triangles() { return kBlockTris; }
@@ -1159,9 +1154,12 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
     FragParams p;
     p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.screen = f.screen; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
     p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness;
-    p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0;
+    p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.dirty = f.dirty;
     const dim3 grid(div_up((uint32_t)f.g.rw, 32), div_up((uint32_t)f.g.rh, 8), f.n_views), block(32, 8);
-    if (f.g.samples == 1) fragment_kernel<1><<<grid, block, 0, st>>>(p);
+    if (f.dirty.flags) {   // the grid is the dirty map's block grid
+        if (f.g.samples == 1) fragment_kernel<1, true><<<grid, block, 0, st>>>(p);
+        else fragment_kernel<4, true><<<grid, block, 0, st>>>(p);
+    } else if (f.g.samples == 1) fragment_kernel<1><<<grid, block, 0, st>>>(p);
     else fragment_kernel<4><<<grid, block, 0, st>>>(p);
 }
 

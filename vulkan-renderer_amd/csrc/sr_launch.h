@@ -17,6 +17,7 @@ struct FragLaunch {
     const float* decode;
     const float* thresh;
     uint32_t view0, n_views;
+    DirtyMap dirty;            // flags == null: every block is shaded from the visibility buffer
 };
 
 void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz);
@@ -24,12 +25,19 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
                    int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out);
 // vis: n words to clear; zero16/zero_bytes: 16-byte aligned block to zero; views_*: optional 16-byte aligned copy (0 bytes = none)
 void launch_begin_pass(hipStream_t st, uint64_t* vis, size_t n, void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes);
+void launch_pack_positions(hipStream_t st, const void* aos, uint32_t n, void* pos4);
+// pos4 != null selects the set-up kernel that transforms vertices itself (packed positions, transforms of the pass's views);
+// the caller then skips launch_vertex
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
-                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between /* recorded between set-up and binning, may be null */);
+                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between /* recorded between set-up and binning, may be null */,
+                  const void* pos4 = nullptr, const ViewXform* views = nullptr, const DirtyMap& dirty = DirtyMap{nullptr, 0, 0});
+// start of a pass when the target keeps a dirty map: vis is the target's whole visibility buffer
+void launch_begin_pass_dirty(hipStream_t st, uint64_t* vis, const FrameGeom& g, uint32_t view0, uint32_t n_views, const DirtyMap& dirty,
+                             void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes);
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters);
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views);
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                   uint64_t* vis, uint32_t view0, uint32_t n_views);
+                   uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty = DirtyMap{nullptr, 0, 0});
 bool raster_config_supported(int samples, int tile_log2);
 uint32_t setup_block_triangles();   // triangles handled by one set-up block
 uint32_t setup_block_records();     // size of the record segment one set-up block owns
