@@ -41,7 +41,7 @@ def test_results_do_not_depend_on_lane_order(order):
     run_gpu_suite_emulated(order, select="soup or huge or golden or split or multi_view or errors or trailing")
 
 
-@pytest.mark.parametrize("variant", ["fused_geometry", "dirty_blocks"])
+@pytest.mark.parametrize("variant", ["fused_geometry", "dirty_blocks,exact_shading"])
 def test_pipeline_variants_give_the_same_frames(variant):
     """The switchable pipeline variants (environment variable SR_VARIANT, see sr_api.hip) must pass the
     same parity suite as the default pipeline."""

@@ -56,6 +56,7 @@ enum : unsigned {
     kVariantFusedGeometry = 1u << 0,   // "fused_geometry": triangle set-up transforms the vertices itself, no vertex pass
     kVariantDirtyBlocks = 1u << 1,     // "dirty_blocks": per-block dirty map; only written blocks are cleared and read back by shading
                                        //                 (the marking lives in the fused set-up kernel, so this implies fused_geometry)
+    kVariantExactShading = 1u << 2,    // "exact_shading": the shading pass recomputes window-space vertices bit-identically to the vertex stage
 };
 
 unsigned parse_variants(const char* text)
@@ -68,6 +69,7 @@ unsigned parse_variants(const char* text)
         const std::string name = s.substr(pos, end - pos);
         if (name == "fused_geometry") v |= kVariantFusedGeometry;
         if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
+        if (name == "exact_shading") v |= kVariantExactShading;
         pos = end + 1;
     }
     return v;
@@ -289,6 +291,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         f.idx = m->d_idx; f.verts_aos = m->d_aos; f.screen = sp; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv; f.dirty = dirty;
+        f.exact_vertices = (dev->variants & kVariantExactShading) != 0;
         launch_fragment(st, f);
         if (ev) SR_HIP(hipEventRecord(ev[8], st));
     }

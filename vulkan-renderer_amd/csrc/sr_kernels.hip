@@ -854,6 +854,12 @@ __device__ inline ScreenVertex shading_vertex(const ViewXform& vx, float px, flo
 // shades triangle `tri` at pixel (x,y): packed B,G,R,A.  Barycentrics are evaluated in float relative
 // to vertex 0 (exact for triangles up to a few hundred pixels, 2^-24 relative otherwise); the values
 // at the other pixels of the 2x2 quad follow from their screen-space gradients.
+// EXACT: the window-space vertices are recomputed with the vertex stage's own arithmetic (IEEE divide,
+// no contraction) and so are bit-identical to the ones the triangle was rasterised from; the default
+// uses the hardware reciprocal, which can land a vertex on the neighbouring 1/256-pixel position --
+// invisible on ordinary triangles, but on slivers a fraction of a pixel wide it shifts the texture
+// gradients (and can collapse the area to zero).
+template <bool EXACT = false>
 __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, size_t sv_base, uint32_t tri, int x, int y,
                                        const float* dec, const float* thr, const uint32_t* lvl /* [3][kMaxMipLevels] */)
 {
@@ -865,9 +871,17 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     // vertex stage's planes: six divergent loads cost the CU's address/cache path far more than
     // ~45 arithmetic instructions per vertex.  (Reciprocal instead of division: at worst a vertex lands
     // on the neighbouring 1/256-pixel position, which moves no colour by an 8-bit step.)
-    const ScreenVertex v0 = shading_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H);
-    const ScreenVertex v1 = shading_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H);
-    const ScreenVertex v2 = shading_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H);
+    ScreenVertex v0, v1, v2;
+    if constexpr (EXACT) {
+        float clip[4];
+        v0 = project_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H, clip);
+        v1 = project_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H, clip);
+        v2 = project_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H, clip);
+    } else {
+        v0 = shading_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H);
+        v1 = shading_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H);
+        v2 = shading_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H);
+    }
     // edge vectors relative to v0, 1/256 pixel; weights: l1 = cross(p - v0, e2) / A', l2 = cross(e1, p - v0) / A'
     const float e1x = (float)(v1.X - v0.X), e1y = (float)(v1.Y - v0.Y);
     const float e2x = (float)(v2.X - v0.X), e2y = (float)(v2.Y - v0.Y);
@@ -918,7 +932,7 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     return B | (G << 8) | (R << 16) | (255u << 24);
 }
 
-template <int S, bool DIRTY = false>
+template <int S, bool DIRTY = false, bool EXACT = false>
 __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
 {
     __shared__ float s_dec[256];
@@ -963,7 +977,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
             for (int k = 0; k < s; ++k) if (k == prev) c = col[k];
             col[s] = c;
         } else {
-            col[s] = shade_pixel(p, vx, sv, ids[s], x, y, s_dec, s_thr, s_lvl);
+            col[s] = shade_pixel<EXACT>(p, vx, sv, ids[s], x, y, s_dec, s_thr, s_lvl);
         }
     }
     uint32_t outc;
@@ -1156,11 +1170,18 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
     p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness;
     p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.dirty = f.dirty;
     const dim3 grid(div_up((uint32_t)f.g.rw, 32), div_up((uint32_t)f.g.rh, 8), f.n_views), block(32, 8);
-    if (f.dirty.flags) {   // the grid is the dirty map's block grid
-        if (f.g.samples == 1) fragment_kernel<1, true><<<grid, block, 0, st>>>(p);
-        else fragment_kernel<4, true><<<grid, block, 0, st>>>(p);
-    } else if (f.g.samples == 1) fragment_kernel<1><<<grid, block, 0, st>>>(p);
-    else fragment_kernel<4><<<grid, block, 0, st>>>(p);
+    const bool dirty = f.dirty.flags != nullptr;   // the grid is the dirty map's block grid
+    if (f.g.samples == 1) {
+        if (dirty && f.exact_vertices) fragment_kernel<1, true, true><<<grid, block, 0, st>>>(p);
+        else if (dirty) fragment_kernel<1, true, false><<<grid, block, 0, st>>>(p);
+        else if (f.exact_vertices) fragment_kernel<1, false, true><<<grid, block, 0, st>>>(p);
+        else fragment_kernel<1><<<grid, block, 0, st>>>(p);
+    } else {
+        if (dirty && f.exact_vertices) fragment_kernel<4, true, true><<<grid, block, 0, st>>>(p);
+        else if (dirty) fragment_kernel<4, true, false><<<grid, block, 0, st>>>(p);
+        else if (f.exact_vertices) fragment_kernel<4, false, true><<<grid, block, 0, st>>>(p);
+        else fragment_kernel<4><<<grid, block, 0, st>>>(p);
+    }
 }
 
 void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh)
