@@ -61,8 +61,8 @@ typedef enum sr_readback_kind {
 typedef struct sr_draw_stats {
     uint64_t vertices;            /* V: vertices transformed */
     uint64_t triangles;           /* T: triangles submitted */
-    uint64_t triangles_binned;    /* surviving triangles that went through the per-tile lists */
-    uint64_t tile_refs;           /* (triangle, tile) references emitted for them */
+    uint64_t triangles_binned;    /* surviving triangles that were not resolved by the set-up kernel itself */
+    uint64_t tile_refs;           /* (triangle, tile) references emitted for them; 0 if they were resolved without tile lists */
     uint64_t triangles_unprojectable; /* dropped: a vertex at w <= 0 or outside the guard band */
     uint64_t shaded_pixels;       /* Pv: pixels with at least one covered sample */
     uint64_t visible_triangles;   /* F: distinct triangles owning at least one sample */

@@ -145,6 +145,7 @@ template <class T> inline T from_bits(uint64_t b) { T v; std::memcpy(&v, &b, siz
 #define HIPEMU_SITE __builtin_extract_return_addr(__builtin_return_address(0))
 
 static inline void __syncthreads() { ::hipemu::barrier(); }
+static inline void __threadfence() {}   // one work-item runs at a time: every store is visible at once
 
 __attribute__((noinline)) static uint64_t hipemu_ballot(bool pred) { return ::hipemu::wave_exchange(0, pred, HIPEMU_SITE).pred_mask; }
 #define __ballot(pred) hipemu_ballot((pred) != 0)

@@ -41,12 +41,19 @@ def test_results_do_not_depend_on_lane_order(order):
     run_gpu_suite_emulated(order, select="soup or huge or golden or split or multi_view or errors or trailing")
 
 
-@pytest.mark.parametrize("variant", ["fused_geometry", "dirty_blocks,exact_shading"])
+VARIANTS = ["fused_geometry", "dirty_blocks,exact_shading", "sparse_tail_force,dirty_blocks", "sparse_tail,dirty_blocks,exact_shading"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_pipeline_variants_give_the_same_frames(variant):
     """The switchable pipeline variants (environment variable SR_VARIANT, see sr_api.hip) must pass the
     same parity suite as the default pipeline."""
     run_gpu_suite_emulated("forward", SR_VARIANT=variant)
-    run_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full", SR_VARIANT=variant)
+
+
+def test_pipeline_variants_do_not_depend_on_lane_order():
+    run_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full or huge", SR_VARIANT="sparse_tail_force,dirty_blocks,exact_shading")
+    run_gpu_suite_emulated("shuffle", select="reused or soup or golden or zz_full or huge", SR_VARIANT="dirty_blocks")
 
 
 def test_full_size_frame_on_emulated_kernels():

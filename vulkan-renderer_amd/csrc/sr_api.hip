@@ -57,7 +57,12 @@ enum : unsigned {
     kVariantDirtyBlocks = 1u << 1,     // "dirty_blocks": per-block dirty map; only written blocks are cleared and read back by shading
                                        //                 (the marking lives in the fused set-up kernel, so this implies fused_geometry)
     kVariantExactShading = 1u << 2,    // "exact_shading": the shading pass recomputes window-space vertices bit-identically to the vertex stage
+    kVariantSparseTail = 1u << 3,      // "sparse_tail": a target whose last frame left few triangles for the tile lists gets one kernel
+                                       //                in place of bin + scan + fill + raster (implies fused_geometry)
+    kVariantSparseTailForce = 1u << 4, // "sparse_tail_force": always take that kernel, whatever the last frame was (for tests)
 };
+// a frame qualifies for the sparse tail when its predecessor stayed under these
+constexpr uint32_t kSparseMaxPending = 4096, kSparseMaxRefs = 16384, kSparseMaxSteps = 65536;
 
 unsigned parse_variants(const char* text)
 {
@@ -70,6 +75,8 @@ unsigned parse_variants(const char* text)
         if (name == "fused_geometry") v |= kVariantFusedGeometry;
         if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "exact_shading") v |= kVariantExactShading;
+        if (name == "sparse_tail") v |= kVariantSparseTail | kVariantFusedGeometry;
+        if (name == "sparse_tail_force") v |= kVariantSparseTailForce | kVariantSparseTail | kVariantFusedGeometry;
         pos = end + 1;
     }
     return v;
@@ -130,6 +137,7 @@ struct sr_target_t {
     uint32_t* h_counters = nullptr; void* hd_counters = nullptr; size_t h_counters_cap = 0;   // pinned + mapped, [passes][8], written by the scan kernel of the last draw
     uint64_t capacity_at_draw = 0;
     uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0;
+    bool sparse = false;        // kVariantSparseTail: the draw being issued (and then: the last draw) uses the sparse tail
 };
 
 namespace {
@@ -278,14 +286,21 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty);
+        const bool sparse = fused && tg->sparse && m->n_tris > 0;
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
-        launch_scan(st, b, nv * n_tiles, nv, (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass);
-        if (ev) SR_HIP(hipEventRecord(ev[5], st));
-        launch_fill(st, g, b, m->n_tris, nv);
-        if (ev) SR_HIP(hipEventRecord(ev[6], st));
-        launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty);
+        uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
+        if (sparse) {   // one kernel resolves whatever set-up left pending; its time is reported as the raster stage
+            if (ev) { SR_HIP(hipEventRecord(ev[5], st)); SR_HIP(hipEventRecord(ev[6], st)); }
+            launch_sparse_tail(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty, pass_counters);
+        } else {
+            launch_scan(st, b, nv * n_tiles, nv, pass_counters);
+            if (ev) SR_HIP(hipEventRecord(ev[5], st));
+            launch_fill(st, g, b, m->n_tris, nv);
+            if (ev) SR_HIP(hipEventRecord(ev[6], st));
+            launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty);
+        }
         if (ev) SR_HIP(hipEventRecord(ev[7], st));
         FragLaunch f{};
         f.idx = m->d_idx; f.verts_aos = m->d_aos; f.screen = sp; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
@@ -614,6 +629,19 @@ int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_block
             }
     }
     (void)hipGetLastError();
+    if (dev->variants & kVariantSparseTail) {
+        // Decide from the counters of this target's previous draw (pinned memory the kernels write; it may still be
+        // in flight, in which case the figures are one frame older -- either way only speed depends on them).
+        bool next = (dev->variants & kVariantSparseTailForce) != 0;
+        if (!next && target->passes > 0 && target->mesh == mesh) {
+            next = true;
+            for (uint32_t p = 0; p < target->passes; ++p) {
+                const uint32_t* c = target->h_counters + (size_t)p * kCountersPerPass;
+                if (c[3] > kSparseMaxPending || (target->sparse ? c[5] > kSparseMaxSteps : c[0] > kSparseMaxRefs)) next = false;
+            }
+        }
+        target->sparse = next;
+    }
     target->mesh = mesh;
     for (int k = 0; k < 4; ++k) target->tex[k] = textures[k];
     target->views.resize(n_views);

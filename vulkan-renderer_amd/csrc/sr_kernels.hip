@@ -653,6 +653,85 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
 }
 
 // =================================================================================================
+// stage 3': sparse tail (pipeline variant).  A frame of sub-pixel triangles leaves next to nothing for
+// the tile lists (115 of 10 M triangles in the 4K sphere frame), yet binning, scan, fill and the
+// per-tile pass each cost a launch.  When the previous frame of a target left few triangles pending
+// the host issues this kernel in their place: every wave takes pending triangles straight from the
+// set-up blocks' lists and resolves them into the visibility buffer in HBM with the same edge
+// functions, depth expression and 64-bit min as every other path, 8x8 pixels per step.  Correct for
+// any number and size of triangles, just not fast for many large ones -- the counters it reports
+// (pending triangles, 8x8 steps) send the next frame back to the tile lists in that case.
+// =================================================================================================
+template <int S>
+__global__ __launch_bounds__(256) void sparse_tail_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp, FrameGeom g, BinBuffers b,
+                                                          unsigned long long* __restrict__ vis, uint32_t view0, uint32_t n_views, DirtyMap dirty,
+                                                          uint32_t* __restrict__ host_counters)
+{
+    __shared__ uint32_t s_sum[3];   // pending triangles, micro-triangles, 8x8 steps
+    if (threadIdx.x < 3u) s_sum[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint32_t waves_total = gridDim.x * 4u, first = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t n_slices = n_views * b.n_blocks;
+    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    uint32_t n_pending = 0, n_micro = 0, n_steps = 0;
+    for (uint32_t slice = first; slice < n_slices; slice += waves_total) {   // one set-up block's list per turn; every lane of the wave holds the same triangle
+        const uint32_t live = b.block_live[slice];
+        const uint32_t count = live & 0xFFFFu, view = slice / b.n_blocks;
+        n_pending += count; n_micro += live >> 16;
+        const int2* xy = sp.xy + (size_t)view * sp.n_verts;
+        const float2* zw = sp.zw + (size_t)view * sp.n_verts;
+        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
+        for (uint32_t t = 0; t < count; ++t) {
+            const uint32_t tri = b.pending[(size_t)slice * kBlockTris + t];
+            if (tri >= n_tris) continue;   // (lists only ever hold valid ids; cheap insurance against a fault)
+            const uint32_t i0 = idx[3 * (size_t)tri], i1 = idx[3 * (size_t)tri + 1], i2 = idx[3 * (size_t)tri + 2];
+            const int2 a0 = xy[i0], a1 = xy[i1], a2 = xy[i2];
+            ScreenVertex v0, v1, v2;
+            v0.X = a0.x; v0.Y = a0.y; v0.z = zw[i0].x; v0.rw = a0.x == kBadVertexX ? 0.0f : 1.0f;
+            v1.X = a1.x; v1.Y = a1.y; v1.z = zw[i1].x; v1.rw = a1.x == kBadVertexX ? 0.0f : 1.0f;
+            v2.X = a2.x; v2.Y = a2.y; v2.z = zw[i2].x; v2.rw = a2.x == kBadVertexX ? 0.0f : 1.0f;
+            TriSetup ts;
+            if (setup_triangle(v0, v1, v2, ts) != 1) continue;
+            int x0, x1, y0, y1;
+            pixel_span<S>(ts.minX, ts.maxX, x0, x1);
+            pixel_span<S>(ts.minY, ts.maxY, y0, y1);
+            x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+            y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+            const bool narrow = fits_32bit(ts);
+            for (int by = y0; by <= y1; by += 8)
+                for (int bx = x0; bx <= x1; bx += 8) {
+                    ++n_steps;
+                    const int x = bx + lx, y = by + ly;
+                    if (x <= x1 && y <= y1) {
+                        unsigned long long* cell = &vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S];
+                        if (narrow) raster_pixel32<S>(ts, tri, x, y, cell);
+                        else raster_pixel<S>(ts, tri, x, y, cell);
+                    }
+                    // the step's four corner lanes mark the (at most four) blocks of the dirty map under it
+                    if (dirty.flags && (lx == 0 || lx == 7) && (ly == 0 || ly == 7))
+                        mark_dirty(dirty, view0 + view, min(x, x1) - g.rx, min(y, y1) - g.ry);
+                }
+        }
+    }
+    if (lane == 0u) { atomicAdd(&s_sum[0], n_pending); atomicAdd(&s_sum[1], n_micro); atomicAdd(&s_sum[2], n_steps); }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        // totals of the pass for the host: the workgroup that finishes last writes them to pinned host memory
+        atomicAdd(&b.counters[3], s_sum[0]); atomicAdd(&b.counters[4], s_sum[1]); atomicAdd(&b.counters[5], s_sum[2]);
+        __threadfence();
+        if (atomicAdd(&b.counters[6], 1u) == gridDim.x - 1u) {
+            __threadfence();
+            host_counters[0] = 0u; host_counters[1] = 0u;
+            host_counters[2] = atomicAdd(&b.counters[2], 0u);
+            host_counters[3] = atomicAdd(&b.counters[3], 0u);
+            host_counters[4] = atomicAdd(&b.counters[4], 0u);
+            host_counters[5] = atomicAdd(&b.counters[5], 0u);
+        }
+    }
+}
+
+// =================================================================================================
 // stage 4: deferred fragment shading (shaders/shader.frag:102-152) from the visibility buffer
 // =================================================================================================
 struct ShadeTables {
@@ -1109,7 +1188,7 @@ void launch_pack_positions(hipStream_t st, const void* aos, uint32_t n, void* po
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between,
-                  const void* pos4, const ViewXform* views, const DirtyMap& dirty)
+                  const void* pos4, const ViewXform* views, const DirtyMap& dirty, bool bin)
 {
     if (!n_tris || !n_views) return;
     const dim3 grid(b.n_blocks, n_views);
@@ -1119,8 +1198,19 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
     } else if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
     else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
     if (between) (void)hipEventRecord(between, st);
+    if (!bin) return;
     if (g.samples == 1) bin_kernel<1><<<grid, 256, 0, st>>>(idx, sp, g, b);
     else bin_kernel<4><<<grid, 256, 0, st>>>(idx, sp, g, b);
+}
+
+void launch_sparse_tail(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
+                        uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty, uint32_t* host_counters)
+{
+    // a few waves per CU; the lists of one pass are dealt out round robin
+    const uint32_t slices = std::max<uint32_t>(b.n_blocks * n_views, 1u);
+    const uint32_t blocks = std::min<uint32_t>((slices + 3u) / 4u, 1024u);
+    if (g.samples == 1) sparse_tail_kernel<1><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
+    else sparse_tail_kernel<4><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
 }
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters)
