@@ -10,58 +10,75 @@ import os
 import subprocess
 import sys
 
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_gpu_suite_emulated(order, select=None, timeout=900, what="tests", **extra_env):
+def start_gpu_suite_emulated(order="forward", select=None, what="tests", **extra_env):
+    """Starts `pytest -m gpu` on the emulated kernels in a child process."""
     env = dict(os.environ, SR_TEST_EMULATED="1", HIPEMU_ORDER=order, **extra_env)
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, what), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"]
     if select:
         cmd += ["-k", select]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
-    tail = "\n".join(r.stdout.splitlines()[-40:])
-    assert r.returncode == 0, f"emulated run ({order}) failed:\n{tail}"
+    label = f"order={order} select={select} {extra_env}"
+    return label, subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def finish(run, timeout=1500):
+    label, proc = run
+    out, _ = proc.communicate(timeout=timeout)
+    tail = "\n".join(out.splitlines()[-40:])
+    assert proc.returncode == 0, f"emulated run ({label}) failed:\n{tail}"
     assert " passed" in tail and "failed" not in tail, tail
     return tail
 
 
+def build_emulation_library():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build()   # once, before child processes race to build it
+
+
 def test_gpu_parity_suite_on_emulated_kernels():
-    """Whole gpu-marked suite, lanes scheduled in ascending order."""
-    tail = run_gpu_suite_emulated("forward")
+    """Whole gpu-marked suite on the default pipeline, lanes scheduled in ascending order; a second and
+    third run of the order-sensitive tests with the lanes of every workgroup in descending and in
+    shuffled order between synchronisation points (a missing barrier or an order-dependent reservation
+    shows up as a parity failure)."""
+    build_emulation_library()
+    subset = "soup or huge or golden or split or multi_view or errors or trailing or reused"
+    runs = [start_gpu_suite_emulated("forward"), start_gpu_suite_emulated("reverse", select=subset), start_gpu_suite_emulated("shuffle", select=subset)]
+    tails = [finish(r) for r in runs]
     # the two tests that need a real GPU process are the only ones allowed to be skipped
-    assert "2 skipped" in tail, tail
+    assert "2 skipped" in tails[0], tails[0]
 
 
-@pytest.mark.parametrize("order", ["reverse", "shuffle"])
-def test_results_do_not_depend_on_lane_order(order):
-    """Same results when the lanes of a workgroup run in another order between synchronisation
-    points: a missing barrier or an order-dependent reservation shows up as a parity failure."""
-    run_gpu_suite_emulated(order, select="soup or huge or golden or split or multi_view or errors or trailing")
+VARIANTS = ["fused_geometry", "dirty_blocks,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
+            "cluster_cull,sparse_tail,dirty_blocks,exact_shading"]
 
 
-VARIANTS = ["fused_geometry", "dirty_blocks,exact_shading", "sparse_tail_force,dirty_blocks", "sparse_tail,dirty_blocks,exact_shading"]
-
-
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_pipeline_variants_give_the_same_frames(variant):
+def test_pipeline_variants_give_the_same_frames():
     """The switchable pipeline variants (environment variable SR_VARIANT, see sr_api.hip) must pass the
-    same parity suite as the default pipeline."""
-    run_gpu_suite_emulated("forward", SR_VARIANT=variant)
-
-
-def test_pipeline_variants_do_not_depend_on_lane_order():
-    run_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full or huge", SR_VARIANT="sparse_tail_force,dirty_blocks,exact_shading")
-    run_gpu_suite_emulated("shuffle", select="reused or soup or golden or zz_full or huge", SR_VARIANT="dirty_blocks")
+    same parity suite as the default pipeline; the combination of all of them also with the lanes in
+    descending order."""
+    build_emulation_library()
+    runs = [start_gpu_suite_emulated("forward", SR_VARIANT=v) for v in VARIANTS]
+    runs.append(start_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full or huge or cluster",
+                                         SR_VARIANT="cluster_cull,sparse_tail_force,dirty_blocks,exact_shading"))
+    for r in runs:
+        finish(r)
 
 
 def test_full_size_frame_on_emulated_kernels():
     """The 10 M-triangle 3840x2160 frame of the headline benchmark, executed on the CPU (about a
     minute), with every result of the hardware's approximate reciprocal / rsqrt / exp2 / log2 moved
-    by up to one ulp: windows against the oracle plus the whole-frame properties."""
-    run_gpu_suite_emulated("forward", what=os.path.join("tests", "test_gpu_zz_full_size.py"), timeout=1500,
-                           SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1")
+    by up to one ulp: windows against the oracle plus the whole-frame properties -- on the default
+    pipeline and on the combination of all variants."""
+    build_emulation_library()
+    what = os.path.join("tests", "test_gpu_zz_full_size.py")
+    runs = [start_gpu_suite_emulated(what=what, SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1"),
+            start_gpu_suite_emulated(what=what, SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1", SR_VARIANT="cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading")]
+    for r in runs:
+        finish(r)
 
 
 def test_out_of_range_access_is_reported(tmp_path):

@@ -141,6 +141,64 @@ def test_target_is_reused_across_different_draws(sr, oracle, device, samples):
             t.destroy()
 
 
+def _random_view(rng, W, H, sr):
+    """Random model matrix (rotation, non-uniform scale, sometimes mirrored, small shift) and camera."""
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    a, b, c, d = q
+    rot = np.array([[a*a+b*b-c*c-d*d, 2*(b*c-a*d), 2*(b*d+a*c)], [2*(b*c+a*d), a*a-b*b+c*c-d*d, 2*(c*d-a*b)], [2*(b*d-a*c), 2*(c*d+a*b), a*a-b*b-c*c+d*d]])
+    scale = np.diag(rng.uniform(0.6, 1.6, size=3) * np.array([1.0, 1.0, rng.choice([1.0, 1.0, -1.0])]))
+    model = np.eye(4, dtype=np.float32)
+    model[:3, :3] = (rot @ scale).astype(np.float32)
+    model[:3, 3] = rng.uniform(-0.3, 0.3, size=3)
+    direction = rng.normal(size=3); direction /= np.linalg.norm(direction)
+    eye = direction * rng.uniform(2.2, 7.0)
+    up = (0.0, 0.0, 1.0) if abs(direction[2]) < 0.9 else (0.0, 1.0, 0.0)
+    view = sr.scene.look_at(eye, rng.uniform(-0.4, 0.4, size=3), up)
+    proj = sr.scene.perspective(np.radians(rng.uniform(20.0, 95.0)), W / H, 0.1, 20.0)
+    return sr.scene.make_ubo(model, view, proj, eye)
+
+
+def test_cluster_culling_never_drops_a_drawn_triangle(sr, oracle, device):
+    """With the pipeline variant cluster_cull_verify the set-up kernel evaluates the cluster test but
+    skips nothing, and counts every triangle of a would-be-skipped cluster that the per-triangle path
+    draws or counts: that count must be zero for any mesh, matrix and camera.  (Without the variant
+    the count is zero by construction; the CPU suite runs this test with the variant on.)"""
+    rng = np.random.default_rng(11)
+    images = sr.scene.material_textures(16)
+    tex = [sr.create_texture(device, im) for im in images]
+    culled = 0
+    try:
+        for case in range(10):
+            X, Y = int(rng.integers(40, 400)), int(rng.integers(30, 300))
+            verts, idx = sr.scene.uv_sphere(X, Y)
+            verts[:, 0:3] *= (1.0 + 0.02 * np.sin(7.0 * verts[:, 6:7] * 6.283) * np.cos(5.0 * verts[:, 7:8] * 3.1416)).astype(np.float32)   # bumps
+            if case % 3 == 2:   # reverse the winding: the inside of the shell faces the camera
+                idx = np.ascontiguousarray(idx.reshape(-1, 3)[:, ::-1]).reshape(-1)
+            mesh = sr.create_mesh_from_data(device, verts, idx)
+            W, H = [(320, 200), (640, 360), (1000, 700), (257, 129)][case % 4]
+            rect = None if case % 2 == 0 else (W // 5, H // 7, W // 2, H // 2)
+            tgt = sr.RenderTarget(device, W, H, samples=1 if case % 4 else 4, n_views=3, rect=rect)
+            try:
+                ubos = np.stack([_random_view(rng, W, H, sr) for _ in range(3)])
+                sr.draw(device, tgt, mesh, ubos, tex)
+                st = tgt.stats()
+                assert st["cull_violations"] == 0, (case, st)
+                culled += st["clusters_culled"]
+                if case < 3:   # and the frame itself is the oracle's
+                    for v in range(3):
+                        ref = oracle.draw(ubos[v], verts, idx, images, W, H, 1 if case % 4 else 4, rect=rect)
+                        util.assert_visibility_equal({"tri": tgt.read_triangle_ids(v), "depth": tgt.read_depth(v)}, ref)
+            finally:
+                tgt.destroy()
+                mesh.destroy()
+    finally:
+        for t in tex:
+            t.destroy()
+    import os
+    if "cluster_cull" in os.environ.get("SR_VARIANT", ""):
+        assert culled > 0, "the variant is on but no cluster was ever skipped: the test checks nothing"
+
+
 def test_multi_view_batch_matches_single_views(sr, oracle, device):
     """BASELINE config 2 in small: a batch of orbit cameras drawn by one call."""
     verts, idx = sr.scene.uv_sphere(32, 32)

@@ -53,7 +53,7 @@ def test_counters_describe_the_frame(sr, frame):
     assert st["triangles"] == T and st["vertices"] == frame["verts"].shape[0] and st["pixels"] == W * H
     assert st["shaded_pixels"] == int(covered.sum())
     assert st["visible_triangles"] == int(np.unique(tri[covered]).size)
-    assert st["triangles_unprojectable"] == 0
+    assert st["triangles_unprojectable"] == 0 and st["cull_violations"] == 0
     # about half of the sphere faces the camera; every surviving triangle went one of the two ways
     assert 0 < st["triangles_direct"] + st["triangles_binned"] <= T
     assert st["tile_refs"] >= st["triangles_binned"] or st["tile_refs"] == 0   # 0: resolved without tile lists (sparse-tail variant)

@@ -60,6 +60,9 @@ enum : unsigned {
     kVariantSparseTail = 1u << 3,      // "sparse_tail": a target whose last frame left few triangles for the tile lists gets one kernel
                                        //                in place of bin + scan + fill + raster (implies fused_geometry)
     kVariantSparseTailForce = 1u << 4, // "sparse_tail_force": always take that kernel, whatever the last frame was (for tests)
+    kVariantClusterCull = 1u << 5,     // "cluster_cull": skip 256-triangle clusters that provably draw nothing (sr_device.h; implies fused_geometry)
+    kVariantClusterVerify = 1u << 6,   // "cluster_cull_verify": evaluate the cluster test but skip nothing; count what skipped clusters
+                                       //                        would have drawn into sr_draw_stats.cull_violations (for tests)
 };
 // a frame qualifies for the sparse tail when its predecessor stayed under these
 constexpr uint32_t kSparseMaxPending = 4096, kSparseMaxRefs = 16384, kSparseMaxSteps = 65536;
@@ -75,6 +78,8 @@ unsigned parse_variants(const char* text)
         if (name == "fused_geometry") v |= kVariantFusedGeometry;
         if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "exact_shading") v |= kVariantExactShading;
+        if (name == "cluster_cull") v |= kVariantClusterCull | kVariantFusedGeometry;
+        if (name == "cluster_cull_verify") v |= kVariantClusterVerify | kVariantClusterCull | kVariantFusedGeometry;
         if (name == "sparse_tail") v |= kVariantSparseTail | kVariantFusedGeometry;
         if (name == "sparse_tail_force") v |= kVariantSparseTailForce | kVariantSparseTail | kVariantFusedGeometry;
         pos = end + 1;
@@ -93,13 +98,14 @@ struct sr_device_t {
     DeviceBuffer screen, tile_count, tile_offset, survivors, survivor_count, refs, views, counters;
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
-    struct Staging { ViewXform* h = nullptr; void* d = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool in_flight = false; };   // h: pinned + mapped, d: its device address
+    struct Staging { ViewXform* h = nullptr; void* d = nullptr; size_t cap = 0 /* bytes */; hipEvent_t ev = nullptr; bool in_flight = false; };   // h: pinned + mapped, d: its device address
     Staging staging[4];
     unsigned staging_next = 0;
     uint64_t ref_capacity = 0;
     size_t scratch_budget = (size_t)16 << 30;
     int tile_log2_override = 0;
     unsigned variants = 0;       // kVariant* bits, from SR_VARIANT
+    uint32_t* d_cull_violations = nullptr;   // kVariantClusterVerify: one counter, accumulated over the passes of a draw
     bool profiling = false;
     std::vector<hipEvent_t> events;   // kNumStageEvents per pass of the last profiled draw
     size_t events_used = 0;
@@ -108,6 +114,8 @@ struct sr_device_t {
 struct sr_mesh_t {
     void* d_aos = nullptr;
     void* d_pos4 = nullptr;      // packed (x, y, z, 1) positions; only with kVariantFusedGeometry
+    ClusterRec* d_clusters = nullptr;   // kVariantClusterCull: one record per 256 consecutive triangles
+    uint32_t n_clusters = 0;
     float *px = nullptr, *py = nullptr, *pz = nullptr;
     uint32_t* d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
@@ -133,11 +141,13 @@ struct sr_target_t {
     sr_mesh mesh = nullptr;
     sr_texture tex[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<ViewXform> views;
+    std::vector<ViewCull> cull_views;   // kVariantClusterCull: one per view, staged behind the transforms
     uint32_t passes = 0;
     uint32_t* h_counters = nullptr; void* hd_counters = nullptr; size_t h_counters_cap = 0;   // pinned + mapped, [passes][8], written by the scan kernel of the last draw
     uint64_t capacity_at_draw = 0;
     uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0;
     bool sparse = false;        // kVariantSparseTail: the draw being issued (and then: the last draw) uses the sparse tail
+    uint64_t cull_violations = 0;   // kVariantClusterVerify: of the last draw
 };
 
 namespace {
@@ -181,6 +191,100 @@ uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameG
     return (uint32_t)std::max<uint64_t>(v, 1);
 }
 
+// One record per kClusterTris consecutive triangles (sr_device.h).  Double precision; the float results are
+// widened on the safe side (larger sphere, wider cone, smaller inradius and perimeter).
+std::vector<ClusterRec> build_clusters(const float* verts /* 8 floats per vertex */, const uint32_t* idx, uint32_t n_tris)
+{
+    const uint32_t n_clusters = (n_tris + kClusterTris - 1) / kClusterTris;
+    std::vector<ClusterRec> out(n_clusters);
+    std::vector<double> normals;
+    for (uint32_t c = 0; c < n_clusters; ++c) {
+        const uint32_t t0 = c * kClusterTris, t1 = std::min(n_tris, t0 + kClusterTris);
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t t = t0; t < t1; ++t)
+            for (int k = 0; k < 3; ++k) {
+                const float* p = verts + 8 * (size_t)idx[3 * (size_t)t + k];
+                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)p[a]); hi[a] = std::max(hi[a], (double)p[a]); }
+            }
+        const double ctr[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+        double r2 = 0.0, sum[3] = {0, 0, 0}, rho_min = 1e300, p_min = 1e300;
+        bool usable = true;
+        normals.clear();
+        for (uint32_t t = t0; t < t1; ++t) {
+            const float* pf[3];
+            double p[3][3];
+            for (int k = 0; k < 3; ++k) {
+                pf[k] = verts + 8 * (size_t)idx[3 * (size_t)t + k];
+                for (int a = 0; a < 3; ++a) p[k][a] = pf[k][a];
+                const double d2 = (p[k][0] - ctr[0]) * (p[k][0] - ctr[0]) + (p[k][1] - ctr[1]) * (p[k][1] - ctr[1]) + (p[k][2] - ctr[2]) * (p[k][2] - ctr[2]);
+                r2 = std::max(r2, d2);
+            }
+            auto same = [&](int i, int j) { return pf[i][0] == pf[j][0] && pf[i][1] == pf[j][1] && pf[i][2] == pf[j][2]; };
+            if (same(0, 1) || same(1, 2) || same(0, 2)) continue;   // two corners coincide: the snapped triangle has zero area whatever the view
+            const double e1[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]}, e2[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
+            const double e3[3] = {p[2][0] - p[1][0], p[2][1] - p[1][1], p[2][2] - p[1][2]};
+            const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const double a2 = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            const double per = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) + std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]) +
+                               std::sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+            if (!(a2 > 1e-12 * per * per)) { usable = false; continue; }   // collinear corners: facing is decided by rounding, never skip
+            for (int a = 0; a < 3; ++a) { normals.push_back(n[a] / a2); sum[a] += n[a] / a2; }
+            rho_min = std::min(rho_min, a2 / per);
+            p_min = std::min(p_min, per);
+        }
+        ClusterRec& rec = out[c];
+        rec.cx = (float)ctr[0]; rec.cy = (float)ctr[1]; rec.cz = (float)ctr[2];
+        rec.r = (float)(std::sqrt(r2) * 1.00001 + 1e-30) + 1e-6f * (std::fabs(rec.cx) + std::fabs(rec.cy) + std::fabs(rec.cz));   // covers the rounding of the centre
+        rec.ax = rec.ay = rec.az = 0.0f; rec.cos_alpha = -2.0f; rec.sin_alpha = 0.0f; rec.rho_min = 0.0f; rec.p_min = 1.0f; rec.pad = 0.0f;
+        const double sl = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+        if (usable && !normals.empty() && sl > 1e-3 * (double)(normals.size() / 3)) {
+            const double ax[3] = {sum[0] / sl, sum[1] / sl, sum[2] / sl};
+            double cmin = 1.0;
+            for (size_t i = 0; i < normals.size(); i += 3) cmin = std::min(cmin, normals[i] * ax[0] + normals[i + 1] * ax[1] + normals[i + 2] * ax[2]);
+            cmin -= 1e-5;   // the float axis and the device's float arithmetic
+            if (cmin > 0.05) {
+                rec.ax = (float)ax[0]; rec.ay = (float)ax[1]; rec.az = (float)ax[2];
+                rec.cos_alpha = (float)cmin; rec.sin_alpha = (float)std::sqrt(1.0 - cmin * cmin) * 1.00001f;
+                rec.rho_min = (float)(rho_min * 0.9999); rec.p_min = (float)(p_min * 0.9999);
+            }
+        }
+    }
+    return out;
+}
+
+// per-view constants of the cluster test, from the same float matrices the kernels use
+ViewCull make_view_cull(const ViewXform& x)
+{
+    double M[16], PV[16], T[16];
+    for (int i = 0; i < 16; ++i) { M[i] = x.model[i]; PV[i] = x.pv[i]; }
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) { double s = 0; for (int k = 0; k < 4; ++k) s += PV[4 * k + r] * M[4 * c + k]; T[4 * c + r] = s; }   // column-major PV * M
+    auto row = [&](int r, double* v, double& t) { v[0] = T[r]; v[1] = T[4 + r]; v[2] = T[8 + r]; t = T[12 + r]; };
+    double R0[3], R1[3], R3[3], t0, t1, t3;
+    row(0, R0, t0); row(1, R1, t1); row(3, R3, t3);
+    const double det = R0[0] * (R1[1] * R3[2] - R1[2] * R3[1]) - R0[1] * (R1[0] * R3[2] - R1[2] * R3[0]) + R0[2] * (R1[0] * R3[1] - R1[1] * R3[0]);
+    auto len = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    ViewCull c{};
+    for (int a = 0; a < 3; ++a) { c.R0[a] = (float)R0[a]; c.R1[a] = (float)R1[a]; c.R3[a] = (float)R3[a]; }
+    c.t0 = (float)t0; c.t1 = (float)t1; c.t3 = (float)t3;
+    c.nR0 = (float)(len(R0) * 1.000001); c.nR1 = (float)(len(R1) * 1.000001); c.nR3 = (float)(len(R3) * 1.000001);
+    c.sigma = det < 0 ? -1.0f : 1.0f;
+    c.absdet = (float)(std::fabs(det) * 0.999999);
+    c.cone_ok = 0.0f;
+    const double scale = len(R0) * len(R1) * len(R3);
+    if (std::fabs(det) > 1e-9 * scale && scale > 0) {
+        // centre of projection: P e + t = 0 (Cramer)
+        const double b0 = -t0, b1 = -t1, b3 = -t3;
+        const double ex = (b0 * (R1[1] * R3[2] - R1[2] * R3[1]) - R0[1] * (b1 * R3[2] - R1[2] * b3) + R0[2] * (b1 * R3[1] - R1[1] * b3)) / det;
+        const double ey = (R0[0] * (b1 * R3[2] - R1[2] * b3) - b0 * (R1[0] * R3[2] - R1[2] * R3[0]) + R0[2] * (R1[0] * b3 - b1 * R3[0])) / det;
+        const double ez = (R0[0] * (R1[1] * b3 - b1 * R3[1]) - R0[1] * (R1[0] * b3 - b1 * R3[0]) + b0 * (R1[0] * R3[1] - R1[1] * R3[0])) / det;
+        if (std::isfinite(ex) && std::isfinite(ey) && std::isfinite(ez) && std::fabs(ex) + std::fabs(ey) + std::fabs(ez) < 1e15) {
+            c.e[0] = (float)ex; c.e[1] = (float)ey; c.e[2] = (float)ez; c.cone_ok = 1.0f;
+        }
+    }
+    return c;
+}
+
 // issues every kernel of one draw (all passes) on the device's stream
 int issue_draw(sr_device_t* dev, sr_target_t* tg)
 {
@@ -209,16 +313,18 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
     SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * setup_block_records() * sizeof(BinRecord)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
-    SR_HIP(dev->views.ensure((size_t)n_views * sizeof(ViewXform)));
+    const bool culling = (dev->variants & kVariantClusterCull) && m->d_clusters && m->d_pos4 && tg->cull_views.size() == n_views;
+    const size_t view_bytes = (size_t)n_views * (sizeof(ViewXform) + (culling ? sizeof(ViewCull) : 0));   // [transforms][cull constants]
+    SR_HIP(dev->views.ensure(view_bytes));
     sr_device_t::Staging& sg = dev->staging[dev->staging_next++ & 3u];
     if (!sg.ev) SR_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
     if (sg.in_flight) { SR_HIP(hipEventSynchronize(sg.ev)); sg.in_flight = false; }
-    if (sg.cap < n_views) {
+    if (sg.cap < view_bytes) {
         if (sg.h) SR_HIP(hipHostFree(sg.h));
         sg.h = nullptr; sg.cap = 0;
-        SR_HIP(hipHostMalloc((void**)&sg.h, (size_t)n_views * sizeof(ViewXform), hipHostMallocMapped));
+        SR_HIP(hipHostMalloc((void**)&sg.h, view_bytes, hipHostMallocMapped));
         SR_HIP(hipHostGetDevicePointer(&sg.d, sg.h, 0));
-        sg.cap = n_views;
+        sg.cap = view_bytes;
     }
     if (tg->h_counters_cap < passes) {
         SR_HIP(hipStreamSynchronize(st));
@@ -237,6 +343,8 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     } else dev->events_used = 0;
 
     std::memcpy(sg.h, tg->views.data(), (size_t)n_views * sizeof(ViewXform));
+    if (culling) std::memcpy((char*)sg.h + (size_t)n_views * sizeof(ViewXform), tg->cull_views.data(), (size_t)n_views * sizeof(ViewCull));
+    if (culling && dev->d_cull_violations) SR_HIP(hipMemsetAsync(dev->d_cull_violations, 0, 4, st));
 
     ScreenPlanes sp{};
     sp.xy = (int2*)dev->screen.ptr;
@@ -278,16 +386,22 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         const DirtyMap dirty = fused && tg->dirty.flags ? tg->dirty : DirtyMap{nullptr, 0, 0};
         if (dirty.flags)
             launch_begin_pass_dirty(st, tg->d_vis, g, v0, nv, dirty, b.count_small, zero_words * 4,
-                                    sg.d, dev->views.ptr, pass == 0 ? (size_t)n_views * sizeof(ViewXform) : 0);
+                                    sg.d, dev->views.ptr, pass == 0 ? view_bytes : 0);
         else
             launch_begin_pass(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples, b.count_small, zero_words * 4,
-                              sg.d, dev->views.ptr, pass == 0 ? (size_t)n_views * sizeof(ViewXform) : 0);
+                              sg.d, dev->views.ptr, pass == 0 ? view_bytes : 0);
         if (pass == 0) { SR_HIP(hipEventRecord(sg.ev, st)); sg.in_flight = true; }
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
         const bool sparse = fused && tg->sparse && m->n_tris > 0;
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse);
+        ClusterCull cull{nullptr, nullptr, nullptr};
+        if (culling) {
+            cull.clusters = m->d_clusters;
+            cull.views = (const ViewCull*)((const char*)dev->views.ptr + (size_t)n_views * sizeof(ViewXform)) + v0;
+            cull.violations = (dev->variants & kVariantClusterVerify) ? dev->d_cull_violations : nullptr;
+        }
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse, cull);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
@@ -392,6 +506,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* e = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(e);
     if (const char* e = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 30;
     dev->variants = parse_variants(std::getenv("SR_VARIANT"));
+    if (dev->variants & kVariantClusterVerify) SR_HIP(hipMalloc((void**)&dev->d_cull_violations, 4));
     *out = dev;
     return SR_OK;
 }
@@ -405,7 +520,7 @@ int sr_device_destroy(sr_device dev)
     dev->screen.release(); dev->tile_count.release(); dev->tile_offset.release(); dev->survivors.release();
     dev->survivor_count.release(); dev->refs.release(); dev->views.release(); dev->counters.release();
     for (auto& sg : dev->staging) { if (sg.h) (void)hipHostFree(sg.h); if (sg.ev) (void)hipEventDestroy(sg.ev); }
-    (void)hipFree(dev->d_decode); (void)hipFree(dev->d_thresh);
+    (void)hipFree(dev->d_decode); (void)hipFree(dev->d_thresh); (void)hipFree(dev->d_cull_violations);
     (void)hipStreamDestroy(dev->stream);
     delete dev;
     return SR_OK;
@@ -442,6 +557,12 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
     if (n_tris) SR_HIP(hipMemcpyAsync(m->d_idx, indices, (size_t)n_tris * 12, hipMemcpyHostToDevice, dev->stream));
     launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
     if (m->d_pos4) launch_pack_positions(dev->stream, m->d_aos, n_vertices, m->d_pos4);
+    if ((dev->variants & kVariantClusterCull) && n_tris) {
+        const std::vector<ClusterRec> recs = build_clusters((const float*)vertices, indices, n_tris);
+        m->n_clusters = (uint32_t)recs.size();
+        SR_HIP(hipMalloc((void**)&m->d_clusters, recs.size() * sizeof(ClusterRec)));
+        SR_HIP(hipMemcpy(m->d_clusters, recs.data(), recs.size() * sizeof(ClusterRec), hipMemcpyHostToDevice));
+    }
     SR_HIP(hipGetLastError());
     SR_HIP(hipStreamSynchronize(dev->stream));   // uploaded on return, like the reference's blocking staging copy
     *out = m;
@@ -452,7 +573,7 @@ int sr_mesh_destroy(sr_device dev, sr_mesh mesh)
 {
     if (!mesh) return SR_OK;
     if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
-    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx); (void)hipFree(mesh->d_pos4);
+    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx); (void)hipFree(mesh->d_pos4); (void)hipFree(mesh->d_clusters);
     delete mesh;
     return SR_OK;
 }
@@ -653,6 +774,9 @@ int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_block
         std::memcpy(x.cam, u + 48, 12);
         x.pad = 0.0f;
     }
+    target->cull_views.clear();
+    if (dev->variants & kVariantClusterCull)
+        for (uint32_t v = 0; v < n_views; ++v) target->cull_views.push_back(make_view_cull(target->views[v]));
     target->drawn = true;
     return issue_draw(dev, target);
 }
@@ -693,6 +817,27 @@ int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)
     out->visible_triangles = h[1];
     out->triangles_binned = target->binned;
     out->triangles_direct = target->micro;
+    if ((dev->variants & kVariantClusterCull) && m->d_clusters && target->cull_views.size() == n_views) {
+        // re-evaluate the cluster test for the draw's views (its device copy may have been overwritten by a later draw)
+        ViewCull* d_cv = nullptr; uint64_t* d_total = nullptr; uint64_t total = 0;
+        hipError_t ce = hipMalloc((void**)&d_cv, (size_t)n_views * sizeof(ViewCull));
+        if (ce == hipSuccess) ce = hipMalloc((void**)&d_total, 8);
+        if (ce == hipSuccess) ce = hipMemcpy(d_cv, target->cull_views.data(), (size_t)n_views * sizeof(ViewCull), hipMemcpyHostToDevice);
+        if (ce == hipSuccess) ce = hipMemsetAsync(d_total, 0, 8, dev->stream);
+        if (ce == hipSuccess) {
+            launch_count_culled_clusters(dev->stream, ClusterCull{m->d_clusters, d_cv, nullptr}, g, m->n_clusters, n_views, d_total);
+            ce = hipStreamSynchronize(dev->stream);
+        }
+        if (ce == hipSuccess) ce = hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_cv); (void)hipFree(d_total);
+        SR_HIP(ce);
+        out->clusters_culled = total;
+        if (dev->d_cull_violations) {   // of the most recent draw on this device
+            uint32_t v = 0;
+            SR_HIP(hipMemcpy(&v, dev->d_cull_violations, 4, hipMemcpyDeviceToHost));
+            out->cull_violations = v;
+        }
+    }
     return SR_OK;
 }
 

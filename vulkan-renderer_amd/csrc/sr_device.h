@@ -233,4 +233,86 @@ __device__ inline void mark_dirty(const DirtyMap& d, uint32_t view, int lx, int 
     d.flags[((size_t)view * d.nby + (ly >> kDirtyLog2H)) * d.nbx + (lx >> kDirtyLog2W)] = 1u;
 }
 
+// Cluster culling (pipeline variant "cluster_cull").  A cluster is 256 consecutive triangles of the index
+// list (one of the four slices a set-up workgroup handles).  At mesh creation each cluster gets a
+// bounding sphere, a cone that contains the unit normals of its triangles, its smallest inradius and
+// its smallest perimeter; at draw time a cluster is skipped before any per-triangle work when the test
+// below PROVES that the per-triangle path would draw nothing from it:
+//   * every point of the sphere is in front of the eye plane and inside the guard band (so no triangle
+//     can be "unprojectable", which is counted), and
+//   * either the sphere's window-space bounds miss the stored rectangle by a pixel or more, or every
+//     triangle is back-facing by a margin that exceeds the largest change snapping and float rounding
+//     can make to its window-space area.
+// Facing in window space follows from object space: with clip = P (p - e) for the 3x3 matrix P made
+// of rows x, y, w of proj*view*model and e the centre of projection, the doubled window-space area is
+//   area2 = -(W H / 4) det(P) ((p0 - e) . N) / (w0 w1 w2),  N = (p1 - p0) x (p2 - p0),
+// and a triangle is drawn only if area2 < 0.
+constexpr uint32_t kClusterTris = 256;
+struct ClusterRec {            // 48 bytes
+    float cx, cy, cz, r;       // bounding sphere, object space
+    float ax, ay, az;          // cone axis (unit)
+    float cos_alpha;           // every triangle normal n has n . axis >= cos_alpha; <= 0: no usable cone
+    float sin_alpha;
+    float rho_min;             // smallest 2*area/perimeter (inradius) of the cluster's triangles, object space
+    float p_min;               // smallest perimeter
+    float pad;
+};
+struct ViewCull {              // 96 bytes, per view, computed on the host in double precision
+    float R0[3], t0;           // rows x, y, w of proj*view*model
+    float R1[3], t1;
+    float R3[3], t3;
+    float e[3];                // centre of projection in object space
+    float sigma;               // sign of det(P)
+    float absdet;              // |det(P)|
+    float nR0, nR1, nR3;       // lengths of the rows' 3-vectors
+    float cone_ok;             // 0: no finite centre of projection (or a degenerate matrix): sphere test only
+    float pad[3];
+};
+struct ClusterCull {
+    const ClusterRec* clusters;   // null: variant off
+    const ViewCull* views;        // views of the pass
+    uint32_t* violations;         // non-null: verification mode -- do not skip, count the triangles of would-be-skipped
+                                  // clusters that the per-triangle path draws or counts (must stay 0)
+};
+
+__device__ inline bool cluster_is_invisible(const ClusterRec& cl, const ViewCull& vc, const FrameGeom& g)
+{
+    const float xc = fmaf(vc.R0[2], cl.cz, fmaf(vc.R0[1], cl.cy, vc.R0[0] * cl.cx)) + vc.t0;
+    const float yc = fmaf(vc.R1[2], cl.cz, fmaf(vc.R1[1], cl.cy, vc.R1[0] * cl.cx)) + vc.t1;
+    const float wc = fmaf(vc.R3[2], cl.cz, fmaf(vc.R3[1], cl.cy, vc.R3[0] * cl.cx)) + vc.t3;
+    const float r = cl.r * 1.0001f;   // slack for the rounding of the three sums above
+    const float dw = r * vc.nR3, dx = r * vc.nR0, dy = r * vc.nR1;
+    const float wmin = wc - dw, wmax = wc + dw;
+    if (!(wmin > 1.0e-4f * wmax)) return false;                      // touches the eye plane (or NaN)
+    const float rmin = 1.0f / wmin, rmax = 1.0f / wmax;
+    const float x_hi = xc + dx, x_lo = xc - dx, y_hi = yc + dy, y_lo = yc - dy;
+    const float umax = fmaxf(x_hi * rmin, x_hi * rmax), umin = fminf(x_lo * rmin, x_lo * rmax);   // NDC bounds of the sphere's box
+    const float vmax = fmaxf(y_hi * rmin, y_hi * rmax), vmin = fminf(y_lo * rmin, y_lo * rmax);
+    const float hw = 0.5f * (float)g.W, hh = 0.5f * (float)g.H;
+    const float U = fmaxf(fabsf(umax), fabsf(umin)), V = fmaxf(fabsf(vmax), fabsf(vmin));
+    if (!(U * hw + hw < 0.5f * kGuardPx && V * hh + hh < 0.5f * kGuardPx)) return false;   // a vertex could leave the guard band
+    // window-space bounds, one pixel of slack (snapping moves a vertex by 1/512 pixel, rounding by far less)
+    const float px_lo = umin * hw + hw - 1.0f, px_hi = umax * hw + hw + 1.0f;
+    const float py_lo = -vmax * hh + hh - 1.0f, py_hi = -vmin * hh + hh + 1.0f;
+    if (px_hi < (float)g.rx || px_lo > (float)(g.rx + g.rw) || py_hi < (float)g.ry || py_lo > (float)(g.ry + g.rh)) return true;
+    // back-face cone
+    if (!(cl.cos_alpha > 0.0f) || vc.cone_ok == 0.0f || !(U <= 4.0f && V <= 4.0f)) return false;
+    const float ex = cl.cx - vc.e[0], ey = cl.cy - vc.e[1], ez = cl.cz - vc.e[2];
+    const float D = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+    if (!(D > 2.0f * r)) return false;
+    const float cosg = fminf(fmaxf(vc.sigma * fmaf(ez, cl.az, fmaf(ey, cl.ay, ex * cl.ax)) / D, -1.0f), 1.0f);
+    const float sing = sqrtf(fmaxf(1.0f - cosg * cosg, 0.0f));
+    const float cosdiff = cosg * cl.cos_alpha + sing * cl.sin_alpha;        // cos(angle(d, axis) - alpha)
+    const float gmin = -(D * cosdiff + r) * 0.999f;                          // every triangle: -(p0 - e) . n >= gmin
+    if (!(gmin > 0.0f)) return false;
+    // |area2| in pixels^2 >= K * gmin * (2 * area_object); it must exceed the error bound
+    // 2*sqrt(2)*delta*perimeter_pixels + 8*delta^2 with delta = snapping + rounding of a window coordinate
+    const float K = hw * hh * vc.absdet * (rmax * rmax * rmax);
+    const float Lx = hw * (vc.nR0 + U * vc.nR3) * rmin, Ly = hh * (vc.nR1 + V * vc.nR3) * rmin;   // pixels per object-space unit, at most
+    const float L = sqrtf(Lx * Lx + Ly * Ly);
+    const float delta = 1.0f / 512.0f + fmaxf((float)g.W, (float)g.H) * (1.0f / 1048576.0f);
+    const float need = 2.0f * (2.8284272f * delta * L + 8.0f * delta * delta / cl.p_min);    // safety factor 2
+    return K * gmin * cl.rho_min >= need;
+}
+
 }  // namespace sr

@@ -221,11 +221,13 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
 }
 
 // Set-up with the vertex stage fused in (see sr_setup_body.inc); pos4: packed positions, views: the
-// transforms of the views of this pass, dirty: optional dirty map (flags == null: not tracked).
+// transforms of the views of this pass, dirty: optional dirty map (flags == null: not tracked), cull: optional
+// cluster culling (clusters == null: off).
 template <int S>
 __global__ __launch_bounds__(256) void geometry_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                        FrameGeom g, BinBuffers b, unsigned long long* __restrict__ vis, uint32_t view0,
-                                                       const float4* __restrict__ pos4, const ViewXform* __restrict__ views, DirtyMap dirty)
+                                                       const float4* __restrict__ pos4, const ViewXform* __restrict__ views, DirtyMap dirty,
+                                                       ClusterCull cull)
 {
 #define SR_SETUP_FUSED 1
 #include "sr_setup_body.inc"
@@ -1145,6 +1147,15 @@ __global__ __launch_bounds__(256) void count_flags_kernel(const uint32_t* __rest
     if (m && lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(total, (unsigned long long)__popcll(m));
 }
 
+// number of (view, cluster) pairs the cluster test skips (instrumentation, not on the timed path)
+__global__ __launch_bounds__(256) void count_culled_clusters_kernel(ClusterCull cull, FrameGeom g, uint32_t n_clusters, uint32_t n_views, unsigned long long* __restrict__ total)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool c = i < n_clusters * n_views && cluster_is_invisible(cull.clusters[i % n_clusters], cull.views[i / n_clusters], g);
+    const uint64_t m = __ballot(c);
+    if (m && lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(total, (unsigned long long)__popcll(m));
+}
+
 // =================================================================================================
 // host launchers
 // =================================================================================================
@@ -1188,13 +1199,13 @@ void launch_pack_positions(hipStream_t st, const void* aos, uint32_t n, void* po
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between,
-                  const void* pos4, const ViewXform* views, const DirtyMap& dirty, bool bin)
+                  const void* pos4, const ViewXform* views, const DirtyMap& dirty, bool bin, const ClusterCull& cull)
 {
     if (!n_tris || !n_views) return;
     const dim3 grid(b.n_blocks, n_views);
     if (pos4) {
-        if (g.samples == 1) geometry_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty);
-        else geometry_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty);
+        if (g.samples == 1) geometry_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty, cull);
+        else geometry_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty, cull);
     } else if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
     else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
     if (between) (void)hipEventRecord(between, st);
@@ -1211,6 +1222,12 @@ void launch_sparse_tail(hipStream_t st, const uint32_t* idx, uint32_t n_tris, co
     const uint32_t blocks = std::min<uint32_t>((slices + 3u) / 4u, 1024u);
     if (g.samples == 1) sparse_tail_kernel<1><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
     else sparse_tail_kernel<4><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
+}
+
+void launch_count_culled_clusters(hipStream_t st, const ClusterCull& cull, const FrameGeom& g, uint32_t n_clusters, uint32_t n_views, uint64_t* total)
+{
+    if (!n_clusters || !n_views) return;
+    count_culled_clusters_kernel<<<div_up((uint64_t)n_clusters * n_views, 256), 256, 0, st>>>(cull, g, n_clusters, n_views, (unsigned long long*)total);
 }
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters)

@@ -32,7 +32,9 @@ void launch_pack_positions(hipStream_t st, const void* aos, uint32_t n, void* po
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between /* recorded between set-up and binning, may be null */,
                   const void* pos4 = nullptr, const ViewXform* views = nullptr, const DirtyMap& dirty = DirtyMap{nullptr, 0, 0},
-                  bool bin = true /* false: set-up only, the caller resolves the pending triangles with launch_sparse_tail */);
+                  bool bin = true /* false: set-up only, the caller resolves the pending triangles with launch_sparse_tail */,
+                  const ClusterCull& cull = ClusterCull{nullptr, nullptr, nullptr});
+void launch_count_culled_clusters(hipStream_t st, const ClusterCull& cull, const FrameGeom& g, uint32_t n_clusters, uint32_t n_views, uint64_t* total);
 // resolves every pending triangle of the pass straight into the visibility buffer (in place of bin + scan + fill + raster)
 // and writes the pass's counters to host_counters: [2] unprojectable, [3] pending triangles, [4] micro-triangles, [5] 8x8 steps
 void launch_sparse_tail(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
