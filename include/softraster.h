@@ -68,7 +68,7 @@ typedef struct sr_draw_stats {
     uint64_t visible_triangles;   /* F: distinct triangles owning at least one sample */
     uint64_t pixels;              /* P: pixels of the stored rectangle */
     uint64_t triangles_direct;    /* micro-triangles resolved by the set-up kernel itself (they cover >= 1 sample) */
-    uint64_t clusters_culled;     /* (view, 256-triangle cluster) pairs skipped before any per-triangle work; 0 unless the
+    uint64_t clusters_culled;     /* (view, 64-triangle cluster) pairs skipped before any per-triangle work; 0 unless the
                                      cluster_cull pipeline variant is on */
     uint64_t cull_violations;     /* cluster_cull_verify variant: triangles of would-be-skipped clusters that the per-triangle
                                      path draws or counts; anything but 0 is a bug */

@@ -60,7 +60,7 @@ enum : unsigned {
     kVariantSparseTail = 1u << 3,      // "sparse_tail": a target whose last frame left few triangles for the tile lists gets one kernel
                                        //                in place of bin + scan + fill + raster (implies fused_geometry)
     kVariantSparseTailForce = 1u << 4, // "sparse_tail_force": always take that kernel, whatever the last frame was (for tests)
-    kVariantClusterCull = 1u << 5,     // "cluster_cull": skip 256-triangle clusters that provably draw nothing (sr_device.h; implies fused_geometry)
+    kVariantClusterCull = 1u << 5,     // "cluster_cull": skip 64-triangle clusters that provably draw nothing (sr_device.h; implies fused_geometry)
     kVariantClusterVerify = 1u << 6,   // "cluster_cull_verify": evaluate the cluster test but skip nothing; count what skipped clusters
                                        //                        would have drawn into sr_draw_stats.cull_violations (for tests)
 };
@@ -114,7 +114,7 @@ struct sr_device_t {
 struct sr_mesh_t {
     void* d_aos = nullptr;
     void* d_pos4 = nullptr;      // packed (x, y, z, 1) positions; only with kVariantFusedGeometry
-    ClusterRec* d_clusters = nullptr;   // kVariantClusterCull: one record per 256 consecutive triangles
+    ClusterRec* d_clusters = nullptr;   // kVariantClusterCull: one record per kClusterTris consecutive triangles
     uint32_t n_clusters = 0;
     float *px = nullptr, *py = nullptr, *pz = nullptr;
     uint32_t* d_idx = nullptr;

@@ -233,8 +233,9 @@ __device__ inline void mark_dirty(const DirtyMap& d, uint32_t view, int lx, int 
     d.flags[((size_t)view * d.nby + (ly >> kDirtyLog2H)) * d.nbx + (lx >> kDirtyLog2W)] = 1u;
 }
 
-// Cluster culling (pipeline variant "cluster_cull").  A cluster is 256 consecutive triangles of the index
-// list (one of the four slices a set-up workgroup handles).  At mesh creation each cluster gets a
+// Cluster culling (pipeline variant "cluster_cull").  A cluster is 64 consecutive triangles of the index
+// list: what one wave of a set-up workgroup handles in one of its four turns, so the decision is the
+// same for every lane of a wave.  At mesh creation each cluster gets a
 // bounding sphere, a cone that contains the unit normals of its triangles, its smallest inradius and
 // its smallest perimeter; at draw time a cluster is skipped before any per-triangle work when the test
 // below PROVES that the per-triangle path would draw nothing from it:
@@ -247,7 +248,7 @@ __device__ inline void mark_dirty(const DirtyMap& d, uint32_t view, int lx, int 
 // of rows x, y, w of proj*view*model and e the centre of projection, the doubled window-space area is
 //   area2 = -(W H / 4) det(P) ((p0 - e) . N) / (w0 w1 w2),  N = (p1 - p0) x (p2 - p0),
 // and a triangle is drawn only if area2 < 0.
-constexpr uint32_t kClusterTris = 256;
+constexpr uint32_t kClusterTris = 64;
 struct ClusterRec {            // 48 bytes
     float cx, cy, cz, r;       // bounding sphere, object space
     float ax, ay, az;          // cone axis (unit)
