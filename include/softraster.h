@@ -31,13 +31,15 @@ typedef enum sr_status {
     SR_ERR_DEVICE = -3,         /* a HIP call failed; sr_last_error_string() has the HIP message */
     SR_ERR_INDEX_OUT_OF_RANGE = -4,
     SR_ERR_UNSUPPORTED = -5,
-    SR_ERR_NO_DEVICE = -6       /* no gfx950 device visible: the library never falls back to the CPU */
+    SR_ERR_NO_DEVICE = -6,      /* no gfx950 device visible: the library never falls back to the CPU */
+    SR_ERR_FILE = -7            /* a file cannot be read, or is not what the reader understands; sr_last_error_string() says why */
 } sr_status;
 
 typedef struct sr_device_t* sr_device;
 typedef struct sr_mesh_t* sr_mesh;
 typedef struct sr_texture_t* sr_texture;
 typedef struct sr_target_t* sr_target;
+typedef struct sr_model_t* sr_model;
 
 /* Sampler state; sr_sampler_default() returns the one src/texture.cpp:246-263 creates. */
 typedef struct sr_sampler_desc {
@@ -105,9 +107,37 @@ SR_API int sr_texture_create_rgba8_srgb(sr_device dev, const void* rgba8, int wi
                                         const sr_sampler_desc* sampler, sr_texture* out);
 SR_API int sr_texture_destroy(sr_device dev, sr_texture tex);
 SR_API int sr_texture_mip_levels(sr_texture tex);
+/* size of level 0 (no reference counterpart: the reference's Texture does not keep it) */
+SR_API int sr_texture_size(sr_texture tex, int* width, int* height);
 /* copies one level (RGBA8, max(1,w>>level) * max(1,h>>level) * 4 bytes) to the host; no reference
  * counterpart (the reference never reads an image back); used to check the mip chain */
 SR_API int sr_texture_read_level(sr_device dev, sr_texture tex, int level, void* host_rgba8, size_t bytes);
+
+/* ---- files.  The reference reads its assets through stb_image and Assimp; neither exists here, so the
+ * library reads the formats the reference's data directory uses: PNG and glTF 2.0 (.gltf / .glb).
+ *
+ * sr_texture_create_from_file replaces create_texture_from_file, src/texture.hpp:20 / src/texture.cpp:273-291:
+ * the file is expanded to 8-bit RGBA as stbi_load(path, ..., STBI_rgb_alpha) does (gray -> R=G=B, no alpha
+ * -> 255, 16-bit -> high byte), then handed to sr_texture_create_rgba8_srgb.  PNG only (no interlace). */
+SR_API int sr_texture_create_from_file(sr_device dev, const char* path, const sr_sampler_desc* sampler, sr_texture* out);
+/* the decoding step alone (host only, no device): *rgba8_out is width*height*4 bytes, released with sr_image_free */
+SR_API int sr_image_read_file(const char* path, void** rgba8_out, int* width, int* height);
+SR_API void sr_image_free(void* rgba8);
+
+/* sr_model_load replaces Model::load, src/model.hpp:24 / src/model.cpp:81-98: one mesh per primitive met on a
+ * depth-first walk of the default scene's nodes; node transforms ignored (src/model.cpp:61-77); position, normal
+ * and first uv set with v flipped (aiProcess_FlipUVs); strips and fans triangulated (aiProcess_Triangulate);
+ * fails like the reference when a primitive has no material ("No material!") or the material's base-colour
+ * texture is not embedded in the file ("Cannot load diffuse texture", src/model.cpp:36-54).
+ * The meshes are owned by the model: sr_model_mesh(model, i) stays valid until sr_model_destroy. */
+SR_API int sr_model_load(sr_device dev, const char* path, sr_model* out);
+SR_API uint32_t sr_model_mesh_count(sr_model model);
+SR_API sr_mesh sr_model_mesh(sr_model model, uint32_t index);
+SR_API int sr_model_destroy(sr_device dev, sr_model model);
+/* the reading step alone (host only: dev may be NULL in sr_model_destroy): arrays as sr_mesh_create takes them */
+SR_API int sr_model_read_file(const char* path, sr_model* out);
+SR_API int sr_model_mesh_data(sr_model model, uint32_t index, const void** vertices, uint32_t* n_vertices,
+                              const uint32_t** indices, uint32_t* n_indices);
 
 /* ---- render target: replaces the swap-chain colour image, the multisampled colour and depth
  * attachments and the clear values (src/main.cpp:377-431, 723-738, 919-921).

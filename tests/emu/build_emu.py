@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "vulkan-renderer_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "libsoftraster_emu.so")
 SOURCES = ("sr_kernels.hip", "sr_api.hip")
-HEADERS = ("sr_device.h", "sr_launch.h", "sr_setup_body.inc")
+HEADERS = ("sr_device.h", "sr_launch.h", "sr_setup_body.inc", "sr_assets.h", "sr_assets.cpp")
 
 _LAUNCH = re.compile(r"([A-Za-z_]\w*(?:<[^<>;()]*>)?)\s*<<<(.*?)>>>\s*\(")
 
@@ -52,7 +52,7 @@ def build(force: bool = False, opt: str = "-O1") -> str:
         units.append(dst)
     cmd = ["g++", "-std=c++17", opt, "-g", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden",
            "-Wl,-Bsymbolic", "-Wno-unknown-pragmas", "-U_FORTIFY_SOURCE",
-           "-I", HERE, "-I", CSRC, *units, os.path.join(HERE, "hipemu.cpp"), "-o", LIB]
+           "-I", HERE, "-I", CSRC, *units, os.path.join(CSRC, "sr_assets.cpp"), os.path.join(HERE, "hipemu.cpp"), "-lz", "-o", LIB]
     subprocess.check_call(cmd)
     return LIB
 

@@ -81,6 +81,55 @@ def test_full_size_frame_on_emulated_kernels():
         finish(r)
 
 
+def test_cpp_host_application_on_emulated_kernels(tmp_path):
+    """The C++ mirror of the reference's host API (vulkan-renderer_amd/host), built against the emulation
+    library: Model::load + create_texture_from_file + draw write the same frame as the Python host does
+    from the same files."""
+    import numpy as np
+    build_emulation_library()
+    import build_emu
+    sys.path.insert(0, os.path.join(ROOT, "vulkan-renderer_amd"))
+    import softraster as sr
+    import test_asset_files as files
+    app = str(tmp_path / "headless_app_emu")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "vulkan-renderer_amd", "host", "headless_app.cpp"), "-o", app,
+                           "-L", os.path.dirname(build_emu.LIB), "-lsoftraster_emu", "-Wl,-rpath," + os.path.dirname(build_emu.LIB)])
+    sphere = sr.scene.uv_sphere(24, 16)
+    quad = sr.scene.screen_quad(z=-0.3, half=1.2)
+    doc, blob = files.make_gltf([quad, sphere])            # node order: sphere (root), then quad -> the quad's frame is the one kept
+    gltf = files.write_gltf(tmp_path, "scene.gltf", doc, blob, "file")
+    images = sr.scene.material_textures(16, seed=2)
+    paths = []
+    for k, im in enumerate(images):
+        paths.append(str(tmp_path / f"map{k}.png"))
+        files.write_png(paths[-1], files._pack_rows(im.reshape(16, 16 * 4).astype(np.int64), 8), 16, 16, 6, 8, filters=[4, 1])
+    out = str(tmp_path / "frame.ppm")
+    r = subprocess.run([app, "160", "120", "8", "8", out, "--model", gltf, "--textures", *paths], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert "mesh with %d indices" % sphere[1].size in r.stdout and "mesh with %d indices" % quad[1].size in r.stdout, r.stdout
+    header, rest = open(out, "rb").read().split(b"\n255\n", 1)
+    assert header == b"P6\n160 120"
+    rgb = np.frombuffer(rest, np.uint8).reshape(120, 160, 3)
+    # the same frame from the Python host, in a child process that loads the emulation library
+    script = f"""
+import sys, numpy as np
+sys.path[:0] = [{os.path.join(ROOT, 'vulkan-renderer_amd')!r}, {os.path.join(ROOT, 'tests')!r}]
+import softraster as sr
+sr.LIB_PATH = {build_emu.LIB!r}
+dev = sr.Device(0)
+model = sr.Model.load(dev, {gltf!r})
+tex = [sr.create_texture_from_file(dev, p) for p in {paths!r}]
+tgt = sr.RenderTarget(dev, 160, 120)
+sr.draw(dev, tgt, model.meshes()[-1], sr.scene.default_camera_ubo(160, 120), tex)
+np.save({str(tmp_path / 'py.npy')!r}, tgt.read_color(0))
+"""
+    subprocess.run([sys.executable, "-c", script], check=True, timeout=300)
+    bgra = np.load(str(tmp_path / "py.npy"))
+    assert (rgb != 0).any()
+    assert np.array_equal(rgb, bgra[..., [2, 1, 0]])
+
+
 def test_out_of_range_access_is_reported(tmp_path):
     """The fence works: a kernel launched with a block shape its indexing does not expect is caught."""
     src = os.path.join(ROOT, "tests", "emu", "selftest_fault.cpp")

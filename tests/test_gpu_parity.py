@@ -199,6 +199,45 @@ def test_cluster_culling_never_drops_a_drawn_triangle(sr, oracle, device):
         assert culled > 0, "the variant is on but no cluster was ever skipped: the test checks nothing"
 
 
+def test_model_and_textures_from_files(sr, oracle, device, tmp_path):
+    """Model::load and create_texture_from_file: a glTF file with two meshes and PNG maps, written here,
+    drawn through the file-taking entry points, equals the oracle's frame of the arrays they were made of."""
+    import test_asset_files as files
+    sphere = sr.scene.uv_sphere(20, 14)
+    quad = sr.scene.screen_quad(z=-0.2, half=1.4, uv_scale=2.0)
+    doc, blob = files.make_gltf([sphere, quad], interleave=True)
+    gltf = files.write_gltf(tmp_path, "scene.glb", doc, blob, "glb")
+    images = sr.scene.material_textures(32, seed=3)
+    paths = []
+    for k, im in enumerate(images):
+        path = str(tmp_path / f"map{k}.png")
+        if k >= 2:   # the reference's metallic / roughness maps are one-channel files
+            files.write_png(path, files._pack_rows(im[..., 0].astype(np.int64), 8), 32, 32, 0, 8, filters=[4, 2, 1])
+        else:
+            files.write_png(path, files._pack_rows(im.reshape(32, 32 * 4).astype(np.int64), 8), 32, 32, 6, 8, filters=[3, 4])
+        paths.append(path)
+    model = sr.Model.load(device, gltf)
+    tex = [sr.create_texture_from_file(device, p) for p in paths]
+    W, H = 240, 160
+    ubo = sr.scene.default_camera_ubo(W, H)
+    try:
+        assert [t.width for t in tex] == [32] * 4 and tex[0].mip_levels == 6
+        meshes = model.meshes()
+        assert len(meshes) == 2 and meshes[0].indices_size == quad[1].size and meshes[1].indices_size == sphere[1].size   # root node first
+        for mesh, (verts, idx) in zip(meshes, (quad, sphere)):
+            tgt = sr.RenderTarget(device, W, H)
+            try:
+                sr.draw(device, tgt, mesh, ubo, tex)
+                got = {"tri": tgt.read_triangle_ids(0), "depth": tgt.read_depth(0), "bgra": tgt.read_color(0)}
+            finally:
+                tgt.destroy()
+            _check_view(got, oracle.draw(ubo, verts, idx, images, W, H))
+    finally:
+        model.destroy()
+        for t in tex:
+            t.destroy()
+
+
 def test_multi_view_batch_matches_single_views(sr, oracle, device):
     """BASELINE config 2 in small: a batch of orbit cameras drawn by one call."""
     verts, idx = sr.scene.uv_sphere(32, 32)

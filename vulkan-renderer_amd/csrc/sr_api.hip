@@ -2,6 +2,7 @@
 // and read-backs.  Thin by design: everything per-vertex, per-triangle or per-pixel runs in the
 // kernels of sr_kernels.hip; there is no CPU rendering path in this library.
 #include "../../include/softraster.h"
+#include "sr_assets.h"
 #include "sr_launch.h"
 
 #include <algorithm>
@@ -127,6 +128,11 @@ struct sr_texture_t {
     sr_sampler_desc samp{};
     uint32_t level_off[kMaxMipLevels] = {};
     size_t total_texels = 0;
+};
+
+struct sr_model_t {
+    std::vector<sr_assets::HostMesh> host;   // as read from the file
+    std::vector<sr_mesh> meshes;             // uploaded copies (sr_model_load), same order
 };
 
 struct sr_target_t {
@@ -468,6 +474,7 @@ const char* sr_status_string(int status)
     case SR_ERR_INDEX_OUT_OF_RANGE: return "vertex index out of range";
     case SR_ERR_UNSUPPORTED: return "unsupported configuration";
     case SR_ERR_NO_DEVICE: return "no gfx950 device";
+    case SR_ERR_FILE: return "file cannot be read";
     default: return "unknown status";
     }
 }
@@ -623,6 +630,13 @@ int sr_texture_destroy(sr_device dev, sr_texture tex)
 
 int sr_texture_mip_levels(sr_texture tex) { return tex ? tex->levels : 0; }
 
+int sr_texture_size(sr_texture tex, int* width, int* height)
+{
+    if (!tex || !width || !height) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *width = tex->w; *height = tex->h;
+    return SR_OK;
+}
+
 int sr_texture_read_level(sr_device dev, sr_texture tex, int level, void* host_rgba8, size_t bytes)
 {
     if (!dev || !tex || !host_rgba8) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -632,6 +646,83 @@ int sr_texture_read_level(sr_device dev, sr_texture tex, int level, void* host_r
     SR_HIP(hipSetDevice(dev->ordinal));
     SR_HIP(hipStreamSynchronize(dev->stream));
     SR_HIP(hipMemcpy(host_rgba8, tex->d_chain + tex->level_off[level], need, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// ---- files ---------------------------------------------------------------------------------------
+int sr_image_read_file(const char* path, void** rgba8_out, int* width, int* height)
+{
+    if (!path || !rgba8_out || !width || !height) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *rgba8_out = nullptr;
+    sr_assets::Image img;
+    std::string err;
+    if (!sr_assets::load_image(path, img, err)) return fail(SR_ERR_FILE, err);
+    void* p = std::malloc(img.rgba.size());
+    if (!p) return fail(SR_ERR_OUT_OF_MEMORY, "host allocation failed");
+    std::memcpy(p, img.rgba.data(), img.rgba.size());
+    *rgba8_out = p; *width = img.width; *height = img.height;
+    return SR_OK;
+}
+
+void sr_image_free(void* rgba8) { std::free(rgba8); }
+
+int sr_texture_create_from_file(sr_device dev, const char* path, const sr_sampler_desc* sampler, sr_texture* out)
+{
+    if (!dev || !path || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    sr_assets::Image img;
+    std::string err;
+    if (!sr_assets::load_image(path, img, err)) return fail(SR_ERR_FILE, "failed to load texture image: " + err);   // src/texture.cpp:281-284
+    return sr_texture_create_rgba8_srgb(dev, img.rgba.data(), img.width, img.height, sampler, out);
+}
+
+int sr_model_read_file(const char* path, sr_model* out)
+{
+    if (!path || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    sr_model_t* m = new sr_model_t();
+    std::string err;
+    if (!sr_assets::load_model(path, m->host, err)) { delete m; return fail(SR_ERR_FILE, err); }
+    *out = m;
+    return SR_OK;
+}
+
+int sr_model_load(sr_device dev, const char* path, sr_model* out)
+{
+    if (!dev || !path || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    sr_model m = nullptr;
+    int rc = sr_model_read_file(path, &m);
+    if (rc != SR_OK) return rc;
+    for (const sr_assets::HostMesh& h : m->host) {
+        sr_mesh mesh = nullptr;
+        rc = sr_mesh_create(dev, h.vertices.data(), (uint32_t)(h.vertices.size() / 8), h.indices.data(), (uint32_t)h.indices.size(), &mesh);
+        if (rc != SR_OK) { const std::string keep = g_last_error; (void)sr_model_destroy(dev, m); g_last_error = keep; *out = nullptr; return rc; }
+        m->meshes.push_back(mesh);
+    }
+    *out = m;
+    return SR_OK;
+}
+
+uint32_t sr_model_mesh_count(sr_model model) { return model ? (uint32_t)model->host.size() : 0u; }
+
+sr_mesh sr_model_mesh(sr_model model, uint32_t index) { return model && index < model->meshes.size() ? model->meshes[index] : nullptr; }
+
+int sr_model_mesh_data(sr_model model, uint32_t index, const void** vertices, uint32_t* n_vertices, const uint32_t** indices, uint32_t* n_indices)
+{
+    if (!model || index >= model->host.size()) return fail(SR_ERR_INVALID_ARGUMENT, "mesh index out of range");
+    const sr_assets::HostMesh& h = model->host[index];
+    if (vertices) *vertices = h.vertices.data();
+    if (n_vertices) *n_vertices = (uint32_t)(h.vertices.size() / 8);
+    if (indices) *indices = h.indices.data();
+    if (n_indices) *n_indices = (uint32_t)h.indices.size();
+    return SR_OK;
+}
+
+int sr_model_destroy(sr_device dev, sr_model model)
+{
+    if (!model) return SR_OK;
+    for (sr_mesh mesh : model->meshes) (void)sr_mesh_destroy(dev, mesh);
+    delete model;
     return SR_OK;
 }
 

@@ -2,10 +2,14 @@
 // (device, textures, mesh, uniform buffer) and the same per-frame work (update_uniform_buffer, draw),
 // with the window, swap chain and presentation replaced by a read-back into a PPM file.
 //
-//   headless_app [width height [x_segments y_segments [out.ppm]]]
+//   headless_app [width height [x_segments y_segments [out.ppm]]] [--model file.gltf|.glb] [--textures albedo.png normal.png metallic.png roughness.png]
+// Without --model the reference's generated UV sphere is drawn (src/main.cpp:94-115), without --textures
+// procedural maps; with them the files go through Model::load (src/main.cpp:289) and
+// create_texture_from_file (src/main.cpp:283-288) and every mesh of the model is drawn.
 #include "renderer_host.hpp"
 
 #include <chrono>
+#include <cstring>
 #include <string>
 
 namespace {
@@ -48,21 +52,57 @@ Texture procedural_texture(vkh::GPUDevice& device, int size, int kind)
     return create_texture(device, px.data(), size, size);
 }
 
+void write_ppm(const std::string& path, const std::vector<std::uint8_t>& bgra, int width, int height)
+{
+    if (FILE* f = std::fopen(path.c_str(), "wb")) {
+        std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+        for (std::size_t i = 0; i < bgra.size(); i += 4) { const std::uint8_t rgb[3] = {bgra[i + 2], bgra[i + 1], bgra[i]}; std::fwrite(rgb, 1, 3, f); }
+        std::fclose(f);
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
-    const int width = argc > 2 ? std::atoi(argv[1]) : init_width, height = argc > 2 ? std::atoi(argv[2]) : init_height;
-    const std::uint32_t xs = argc > 4 ? std::atoi(argv[3]) : 88, ys = argc > 4 ? std::atoi(argv[4]) : 88;
-    const std::string out = argc > 5 ? argv[5] : "frame.ppm";
+    int npos = 1;   // positional arguments end at the first option
+    while (npos < argc && std::strncmp(argv[npos], "--", 2) != 0) ++npos;
+    const int width = npos > 2 ? std::atoi(argv[1]) : init_width, height = npos > 2 ? std::atoi(argv[2]) : init_height;
+    const std::uint32_t xs = npos > 4 ? std::atoi(argv[3]) : 88, ys = npos > 4 ? std::atoi(argv[4]) : 88;
+    const std::string out = npos > 5 ? argv[5] : "frame.ppm";
+
+    const char* model_path = nullptr;
+    const char* texture_paths[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int a = 1; a < argc; ++a) {
+        if (!std::strcmp(argv[a], "--model") && a + 1 < argc) model_path = argv[a + 1];
+        if (!std::strcmp(argv[a], "--textures") && a + 4 < argc) for (int k = 0; k < 4; ++k) texture_paths[k] = argv[a + 1 + k];
+    }
 
     vkh::GPUDevice device;                                   // Application(): device_{window_}
-    Texture albedo = procedural_texture(device, 2048, 0);    // init_vulkan(): four textures, then the model
-    Texture normal = procedural_texture(device, 64, 1);
-    Texture metallic = procedural_texture(device, 2048, 2);
-    Texture roughness = procedural_texture(device, 2048, 3);
-    StaticMesh mesh = generate_uv_sphere(device, xs, ys);
+    // init_vulkan(): four textures, then the model
+    Texture albedo = texture_paths[0] ? create_texture_from_file(device, texture_paths[0]) : procedural_texture(device, 2048, 0);
+    Texture normal = texture_paths[1] ? create_texture_from_file(device, texture_paths[1]) : procedural_texture(device, 64, 1);
+    Texture metallic = texture_paths[2] ? create_texture_from_file(device, texture_paths[2]) : procedural_texture(device, 2048, 2);
+    Texture roughness = texture_paths[3] ? create_texture_from_file(device, texture_paths[3]) : procedural_texture(device, 2048, 3);
     RenderTarget target(device, width, height);
+    if (model_path) {
+        // The reference loads the model (src/main.cpp:289) but records the draw of its generated sphere; drawing the
+        // model's meshes is what a user of Model::load wants to see.  One frame per mesh, last one kept.
+        Model model = Model::load(device, model_path);
+        const vec3 eye{2.0f, 2.0f, 2.0f};
+        const UniformBufferObject view = {identity(), look_at(eye, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}),
+                                          perspective(radians(45.0f), static_cast<float>(width) / static_cast<float>(height), 0.1f, 10.0f), eye};
+        for (const Model::Mesh& m : model.meshes()) {
+            target.draw(m, view, albedo, normal, metallic, roughness);
+            const sr_draw_stats st = target.stats();
+            std::printf("mesh with %u indices: %llu shaded pixels, %llu visible triangles\n", m.indices_size,
+                        static_cast<unsigned long long>(st.shaded_pixels), static_cast<unsigned long long>(st.visible_triangles));
+        }
+        write_ppm(out, target.read_color_bgra(), width, height);
+        destroy_texture(device, albedo); destroy_texture(device, normal); destroy_texture(device, metallic); destroy_texture(device, roughness);
+        return 0;
+    }
+    StaticMesh mesh = generate_uv_sphere(device, xs, ys);
 
     const vec3 camera_pos{2.0f, 2.0f, 2.0f}, up{0.0f, 0.0f, 1.0f};   // src/main.cpp:210-211
     const UniformBufferObject ubo = {                                 // update_uniform_buffer, src/main.cpp:988-1004
@@ -81,12 +121,7 @@ int main(int argc, char** argv)
     std::printf("%dx%d, %llu triangles: %.3f ms/frame, %llu shaded pixels, %llu visible triangles\n", width, height,
                 static_cast<unsigned long long>(st.triangles), ms, static_cast<unsigned long long>(st.shaded_pixels),
                 static_cast<unsigned long long>(st.visible_triangles));
-    const std::vector<std::uint8_t> bgra = target.read_color_bgra();
-    if (FILE* f = std::fopen(out.c_str(), "wb")) {
-        std::fprintf(f, "P6\n%d %d\n255\n", width, height);
-        for (std::size_t i = 0; i < bgra.size(); i += 4) { const std::uint8_t rgb[3] = {bgra[i + 2], bgra[i + 1], bgra[i]}; std::fwrite(rgb, 1, 3, f); }
-        std::fclose(f);
-    }
+    write_ppm(out, target.read_color_bgra(), width, height);
     destroy_texture(device, albedo); destroy_texture(device, normal); destroy_texture(device, metallic); destroy_texture(device, roughness);
     return 0;
 }

@@ -139,11 +139,59 @@ struct Texture {               // plain struct with manual destroy, as in src/te
     return t;
 }
 
+// src/texture.hpp:20 / src/texture.cpp:273-291 (PNG files; stb's STBI_rgb_alpha expansion)
+[[nodiscard]] inline Texture create_texture_from_file(vkh::GPUDevice& device, const char* texture_path)
+{
+    Texture t;
+    SRH_CHECK(sr_texture_create_from_file(device.device(), texture_path, nullptr, &t.image));
+    t.mip_levels = static_cast<std::uint32_t>(sr_texture_mip_levels(t.image));
+    return t;
+}
+
 inline void destroy_texture(vkh::GPUDevice& device, Texture& texture)
 {
     sr_texture_destroy(device.device(), texture.image);
     texture.image = nullptr;
 }
+
+// src/model.hpp:9-26: the meshes of a glTF file, one per primitive in node order.  The library owns the
+// uploaded meshes; Mesh is the non-owning view the draw call takes.
+class Model {
+public:
+    struct Mesh {
+        sr_mesh mesh = nullptr;
+        std::uint32_t indices_size = 0;
+        [[nodiscard]] sr_mesh handle() const noexcept { return mesh; }
+    };
+    Model() = default;
+    ~Model() { if (model_) sr_model_destroy(device_, model_); }
+    Model(Model&& o) noexcept : device_(o.device_), model_(std::exchange(o.model_, nullptr)), meshes_(std::move(o.meshes_)) {}
+    Model& operator=(Model&& o) noexcept
+    {
+        if (this != &o) { if (model_) sr_model_destroy(device_, model_); device_ = o.device_; model_ = std::exchange(o.model_, nullptr); meshes_ = std::move(o.meshes_); }
+        return *this;
+    }
+    Model(const Model&) = delete;
+    Model& operator=(const Model&) = delete;
+    [[nodiscard]] const std::vector<Mesh>& meshes() const { return meshes_; }
+    [[nodiscard]] static Model load(vkh::GPUDevice& device, const char* path)
+    {
+        Model m;
+        m.device_ = device.device();
+        SRH_CHECK(sr_model_load(device.device(), path, &m.model_));
+        for (std::uint32_t i = 0; i < sr_model_mesh_count(m.model_); ++i) {
+            std::uint32_t n_indices = 0;
+            SRH_CHECK(sr_model_mesh_data(m.model_, i, nullptr, nullptr, nullptr, &n_indices));
+            m.meshes_.push_back({sr_model_mesh(m.model_, i), n_indices});
+        }
+        return m;
+    }
+
+private:
+    sr_device device_ = nullptr;
+    sr_model model_ = nullptr;
+    std::vector<Mesh> meshes_;
+};
 
 // Stands for the swap-chain image plus the multisampled colour and depth attachments
 // (src/main.cpp:723-738) and for draw_frame's submit (src/main.cpp:1006-1076).
@@ -159,7 +207,8 @@ public:
     RenderTarget& operator=(const RenderTarget&) = delete;
 
     // albedo, normal, metallic, roughness: the descriptor bindings 1-4 of src/main.cpp:461-516
-    void draw(const StaticMesh& mesh, const UniformBufferObject& ubo, const Texture& albedo, const Texture& normal,
+    template <class MeshT>   // StaticMesh or Model::Mesh
+    void draw(const MeshT& mesh, const UniformBufferObject& ubo, const Texture& albedo, const Texture& normal,
               const Texture& metallic, const Texture& roughness)
     {
         const sr_texture tex[4] = {albedo.image, normal.image, metallic.image, roughness.image};

@@ -29,6 +29,8 @@ EXPORTED_SYMBOLS = (
     "sr_mesh_create", "sr_mesh_destroy", "sr_sampler_default", "sr_texture_create_rgba8_srgb", "sr_texture_destroy",
     "sr_texture_mip_levels", "sr_texture_read_level", "sr_target_create", "sr_target_destroy", "sr_target_bind_color",
     "sr_target_readback", "sr_draw", "sr_draw_get_stats", "sr_profile_enable", "sr_profile_get", "sr_debug_vertex_stage",
+    "sr_texture_size", "sr_texture_create_from_file", "sr_image_read_file", "sr_image_free",
+    "sr_model_load", "sr_model_mesh_count", "sr_model_mesh", "sr_model_destroy", "sr_model_read_file", "sr_model_mesh_data",
 )
 
 
@@ -97,6 +99,19 @@ def load_library():
     L.sr_profile_enable.argtypes = [vp, C.c_int]
     L.sr_profile_get.argtypes = [vp, C.POINTER(StageTimes)]
     L.sr_debug_vertex_stage.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.sr_texture_size.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sr_texture_create_from_file.argtypes = [vp, C.c_char_p, C.POINTER(SamplerDesc), C.POINTER(vp)]
+    L.sr_image_read_file.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sr_image_free.argtypes = [vp]
+    L.sr_image_free.restype = None
+    L.sr_model_load.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    L.sr_model_read_file.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.sr_model_mesh_count.argtypes = [vp]
+    L.sr_model_mesh_count.restype = u32
+    L.sr_model_mesh.argtypes = [vp, u32]
+    L.sr_model_mesh.restype = vp
+    L.sr_model_destroy.argtypes = [vp, vp]
+    L.sr_model_mesh_data.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(vp), C.POINTER(u32)]
     _lib = L
     return L
 
@@ -216,6 +231,79 @@ def create_texture(device: Device, data: np.ndarray, tex_width: int | None = Non
 
 def destroy_texture(device: Device, texture: Texture):
     texture.destroy()
+
+
+def read_image(path: str) -> np.ndarray:
+    """Decodes an image file to (h,w,4) uint8 RGBA the way stbi_load(path, ..., STBI_rgb_alpha) expands it
+    (src/texture.cpp:278-279).  Host only.  PNG files."""
+    L = load_library()
+    p, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    _check(L.sr_image_read_file(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)), "sr_image_read_file")
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        L.sr_image_free(p)
+
+
+def create_texture_from_file(device: Device, texture_path: str, sampler: SamplerDesc | None = None) -> Texture:
+    """src/texture.hpp:20 / src/texture.cpp:273-291."""
+    h = C.c_void_p()
+    _check(device._lib.sr_texture_create_from_file(device._h, os.fsencode(texture_path), C.byref(sampler) if sampler is not None else None,
+                                                   C.byref(h)), "sr_texture_create_from_file")
+    w, ht = C.c_int(), C.c_int()
+    _check(device._lib.sr_texture_size(h, C.byref(w), C.byref(ht)), "sr_texture_size")
+    return Texture(device, h, w.value, ht.value)
+
+
+def _model_arrays(L, handle):
+    out = []
+    for i in range(L.sr_model_mesh_count(handle)):
+        v, nv, ix, ni = C.c_void_p(), C.c_uint32(), C.c_void_p(), C.c_uint32()
+        _check(L.sr_model_mesh_data(handle, i, C.byref(v), C.byref(nv), C.byref(ix), C.byref(ni)), "sr_model_mesh_data")
+        verts = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_float)), shape=(nv.value, 8)).copy() if nv.value else np.zeros((0, 8), np.float32)
+        idx = np.ctypeslib.as_array(C.cast(ix, C.POINTER(C.c_uint32)), shape=(ni.value,)).copy() if ni.value else np.zeros(0, np.uint32)
+        out.append((verts, idx))
+    return out
+
+
+def read_model(path: str):
+    """The reading half of Model.load, host only: a list of (vertices (n,8) f32, indices u32), one per
+    primitive in node order."""
+    L = load_library()
+    h = C.c_void_p()
+    _check(L.sr_model_read_file(os.fsencode(path), C.byref(h)), "sr_model_read_file")
+    try:
+        return _model_arrays(L, h)
+    finally:
+        L.sr_model_destroy(None, h)
+
+
+class Model:
+    """src/model.hpp:9-26: the meshes of a glTF file, uploaded."""
+
+    def __init__(self, device: Device, handle):
+        self._dev, self._h = device, handle
+        L = device._lib
+        self._meshes = []
+        for i, (verts, idx) in enumerate(_model_arrays(L, handle)):
+            m = StaticMesh(device, C.c_void_p(L.sr_model_mesh(handle, i)), verts.shape[0], int(idx.size))
+            m.destroy = lambda: None   # owned by the model
+            self._meshes.append(m)
+
+    def meshes(self):
+        return self._meshes
+
+    @staticmethod
+    def load(device: Device, path: str) -> "Model":
+        h = C.c_void_p()
+        _check(device._lib.sr_model_load(device._h, os.fsencode(path), C.byref(h)), "sr_model_load")
+        return Model(device, h)
+
+    def destroy(self):
+        if self._h:
+            self._dev._lib.sr_model_destroy(self._dev._h, self._h)
+            self._h = None
+            self._meshes = []
 
 
 class RenderTarget:
