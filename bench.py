@@ -231,7 +231,7 @@ def main():
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": int(by[dom])},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: the other ranks would sit in the final barrier meanwhile
             from oracle import oracle
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             chains = [(oracle.build_mip_chain(im), im.shape[1], im.shape[0]) if im is not None else (np.zeros((1, 4), np.uint8), 1, 1) for im in images]
