@@ -63,6 +63,11 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_anisotropic(on: bool):
+    """Switches the specification's anisotropic footprint on or off for every later sample (off by default)."""
+    lib().sro_set_anisotropic(1 if on else 0)
+
+
 def srgb_tables():
     dec = np.empty(256, np.float32)
     thr = np.empty(255, np.float32)

@@ -17,6 +17,8 @@ def pytest_configure(config):
 def oracle():
     from oracle import oracle as o
     o.build()
+    # the "anisotropic" pipeline variant is checked against the oracle's anisotropic footprint
+    o.set_anisotropic("anisotropic" in os.environ.get("SR_VARIANT", ""))
     return o
 
 

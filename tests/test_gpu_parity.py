@@ -296,7 +296,9 @@ def test_golden_fixtures(sr, device):
         sc = make_golden.build_scene(name)
         g = np.load(make_golden.path_of(name))
         got = util.gpu_render(sr, device, sc["verts"], sc["idx"], sc["images"], sc["ubo"], sc["width"], sc["height"], sc["samples"])[0]
-        _check_view(got, {"tri": g["tri"], "depth": g["depth"], "bgra": g["bgra"]})
+        # the committed colours are isotropic: with the "anisotropic" pipeline variant only visibility is comparable
+        import os
+        _check_view(got, {"tri": g["tri"], "depth": g["depth"], "bgra": g["bgra"]}, check_color="anisotropic" not in os.environ.get("SR_VARIANT", ""))
 
 
 def test_cpp_host_app_matches_python_host(sr, device, tmp_path):

@@ -143,3 +143,53 @@ def test_constant_textures_give_the_shader_colour_everywhere(oracle):
     got = r["bgra"][y, x, [2, 1, 0]].astype(int)
     for c in range(3):
         assert abs(int(got[c]) - oracle.srgb_encode8(min(want[c], 1.0))) <= 2   # facetted normal vs true sphere normal
+
+
+def test_anisotropic_footprint_is_the_specification_s(oracle):
+    """Switched on, the oracle's texture() follows the Vulkan specification's worked method: eta =
+    min(rho_max / rho_min, 16), N = ceil(eta) trilinear samples at i/(N+1) - 1/2 along the major axis'
+    derivative, level of detail log2(rho_max / eta).  Checked by rebuilding the result from isotropic
+    single-level samples (zero derivatives select level 0; a tap at level k is taken from a texture whose
+    level 0 is that level)."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(64, 64, 4), dtype=np.uint8)
+    img[..., 3] = 255
+    chain = oracle.build_mip_chain(img)
+    levels = [oracle.chain_level(chain, 64, 64, l) for l in range(7)]
+    level_chains = [oracle.build_mip_chain(np.ascontiguousarray(l)) for l in levels]
+
+    def at_level(k, s, t):   # bilinear sample of level k alone
+        side = 64 >> k
+        return oracle.sample(level_chains[k], side, side, s, t)[0]
+
+    s0, t0 = 0.37, 0.61
+    try:
+        oracle.set_anisotropic(True)
+        for (dsdx, dtdx, dsdy, dtdy) in [(8 / 64, 0, 0, 0.5 / 64),          # ratio 16: N = 16, lambda = log2(8/16) -> level 0
+                                         (0, 0.4 / 64, 3.2 * 0.4 / 64 * 4, 0),  # y major, ratio 12.8: N = 13, lambda = log2(5.12/12.8) -> level 0
+                                         (12 / 64, 0, 0, 3 / 64),            # ratio 4: N = 4, lambda = log2(3) = 1.585 -> levels 1 and 2
+                                         (40 / 64, 0, 0, 1 / 64)]:           # ratio 40 capped to 16: lambda = log2(2.5) = 1.32
+            got, _ = oracle.sample(chain, 64, 64, s0, t0, dsdx, dtdx, dsdy, dtdy)
+            rx, ry = np.hypot(dsdx * 64, dtdx * 64), np.hypot(dsdy * 64, dtdy * 64)
+            rmax, rmin = max(rx, ry), min(rx, ry)
+            eta = min(rmax / rmin, 16.0)
+            n = int(np.ceil(np.float32(eta)))
+            lam = max(float(np.log2(np.float32(rmax) / np.float32(eta))), 0.0)
+            lo, frac = int(np.floor(lam)), np.float32(lam) - np.floor(np.float32(lam))
+            ds, dt = (dsdx, dtdx) if rx > ry else (dsdy, dtdy)
+            acc = np.zeros(4, np.float32)
+            for i in range(1, n + 1):
+                off = np.float32(i) / np.float32(n + 1) - np.float32(0.5)
+                s, t = np.float32(s0) + off * np.float32(ds), np.float32(t0) + off * np.float32(dt)
+                tap = at_level(lo, s, t)
+                if frac != 0:
+                    tap = (np.float32(1) - frac) * tap + frac * at_level(lo + 1, s, t)
+                acc += tap
+            assert np.allclose(got, acc / np.float32(n), atol=2e-6), (dsdx, dsdy, got, acc / n)
+        # equal axes: one sample, identical to the isotropic result
+        iso_like, _ = oracle.sample(chain, 64, 64, s0, t0, 2 / 64, 0, 0, 2 / 64)
+        oracle.set_anisotropic(False)
+        iso, _ = oracle.sample(chain, 64, 64, s0, t0, 2 / 64, 0, 0, 2 / 64)
+        assert np.array_equal(iso_like, iso)
+    finally:
+        oracle.set_anisotropic(False)

@@ -62,6 +62,8 @@ enum : unsigned {
                                        //                in place of bin + scan + fill + raster (implies fused_geometry)
     kVariantSparseTailForce = 1u << 4, // "sparse_tail_force": always take that kernel, whatever the last frame was (for tests)
     kVariantClusterCull = 1u << 5,     // "cluster_cull": skip 64-triangle clusters that provably draw nothing (sr_device.h; implies fused_geometry)
+    kVariantAnisotropic = 1u << 7,     // "anisotropic": the sampler's maxAnisotropy (src/texture.cpp:255-256) is applied, by the method the
+                                       //                Vulkan specification spells out (implies dirty_blocks, exact_shading, fused_geometry)
     kVariantClusterVerify = 1u << 6,   // "cluster_cull_verify": evaluate the cluster test but skip nothing; count what skipped clusters
                                        //                        would have drawn into sr_draw_stats.cull_violations (for tests)
 };
@@ -79,6 +81,7 @@ unsigned parse_variants(const char* text)
         if (name == "fused_geometry") v |= kVariantFusedGeometry;
         if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "exact_shading") v |= kVariantExactShading;
+        if (name == "anisotropic") v |= kVariantAnisotropic | kVariantExactShading | kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "cluster_cull") v |= kVariantClusterCull | kVariantFusedGeometry;
         if (name == "cluster_cull_verify") v |= kVariantClusterVerify | kVariantClusterCull | kVariantFusedGeometry;
         if (name == "sparse_tail") v |= kVariantSparseTail | kVariantFusedGeometry;
@@ -427,6 +430,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv; f.dirty = dirty;
         f.exact_vertices = (dev->variants & kVariantExactShading) != 0;
+        f.max_anisotropy = (dev->variants & kVariantAnisotropic) ? std::max(albedo->samp.max_anisotropy, 1.0f) : 1.0f;
         launch_fragment(st, f);
         if (ev) SR_HIP(hipEventRecord(ev[8], st));
     }

@@ -822,6 +822,56 @@ __device__ inline void sample_texture(const TexDesc& t, const uint32_t* lvl, flo
     for (int c = 0; c < NCH; ++c) o[c] = (1.0f - delta) * chi[c] + delta * clo[c];
 }
 
+// texture() with the sampler's anisotropy applied, by the method the Vulkan specification spells out (Scale
+// Factor Operation / Texel Anisotropic Filtering): eta = min(rho_max / rho_min, max_aniso), N = ceil(eta),
+// level of detail from rho_max / eta, and the mean of N trilinear samples placed at i / (N + 1) - 1/2,
+// i = 1..N, along the derivative of the major axis.  Pipeline variant "anisotropic" only.
+template <int NCH>
+__device__ inline void sample_texture_aniso(const TexDesc& t, const uint32_t* lvl, float max_aniso, float s, float tt, float dsdx, float dtdx,
+                                            float dsdy, float dtdy, const float* dec, float* o)
+{
+    const float mux = dsdx * (float)t.w, mvx = dtdx * (float)t.h;
+    const float muy = dsdy * (float)t.w, mvy = dtdy * (float)t.h;
+    const float rx2 = mux * mux + mvx * mvx, ry2 = muy * muy + mvy * mvy;
+    const bool x_major = rx2 > ry2;
+    const float rmax = sqrtf(x_major ? rx2 : ry2), rmin = sqrtf(x_major ? ry2 : rx2);
+    float eta = 1.0f;
+    if (rmax > 0.0f) {
+        eta = rmin > 0.0f ? rmax * __builtin_amdgcn_rcpf(rmin) : max_aniso;
+        if (!(eta < max_aniso)) eta = max_aniso;
+        if (!(eta > 1.0f)) eta = 1.0f;
+    }
+    const int n = (int)ceilf(eta);
+    float lambda = __builtin_amdgcn_logf(rmax * __builtin_amdgcn_rcpf(eta)) + t.bias;
+    if (!(lambda > t.min_lod)) lambda = t.min_lod;
+    if (lambda > t.max_lod) lambda = t.max_lod;
+    const float q = (float)(t.levels - 1);
+    float d = lambda; if (d < 0.0f) d = 0.0f; if (d > q) d = q;
+    const float dhi = floorf(d), delta = d - dhi;
+    const int lhi = (int)dhi, llo = min(lhi + 1, t.levels - 1);
+    const float ds = x_major ? dsdx : dsdy, dt = x_major ? dtdx : dtdy;
+    const float step = __builtin_amdgcn_rcpf((float)(n + 1));
+    float acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = 0.0f;
+    for (int i = 1; i <= n; ++i) {
+        const float off = (float)i * step - 0.5f, si = s + off * ds, ti = tt + off * dt;
+        float chi[NCH];
+        sample_level<NCH>(t, lvl, lhi, si, ti, dec, chi);
+        if (delta != 0.0f) {
+            float clo[NCH];
+            sample_level<NCH>(t, lvl, llo, si, ti, dec, clo);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) chi[c] = (1.0f - delta) * chi[c] + delta * clo[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] += chi[c];
+    }
+    const float inv = __builtin_amdgcn_rcpf((float)n);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) o[c] = acc[c] * inv;
+}
+
 // Colour arithmetic below is allowed 1 LSB of the 8-bit result against the CPU oracle, so it uses
 // the hardware reciprocal / reciprocal-square-root / exp2 / log2 (1 ulp) instead of IEEE division.
 // Nothing here feeds coverage, depth or triangle ids.
@@ -913,6 +963,7 @@ struct FragParams {
     ShadeTables tab;
     uint32_t view0;            // first view of this pass inside the target
     DirtyMap dirty;            // read by fragment_kernel<S, true> only
+    float max_aniso;           // the sampler's maxAnisotropy; used by fragment_kernel<S, true, true, true> only
 };
 
 // window-space position and 1/w of a vertex of a visible triangle (so w > 0), for interpolation only
@@ -940,7 +991,7 @@ __device__ inline ScreenVertex shading_vertex(const ViewXform& vx, float px, flo
 // uses the hardware reciprocal, which can land a vertex on the neighbouring 1/256-pixel position --
 // invisible on ordinary triangles, but on slivers a fraction of a pixel wide it shifts the texture
 // gradients (and can collapse the area to zero).
-template <bool EXACT = false>
+template <bool EXACT = false, bool ANISO = false>
 __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, size_t sv_base, uint32_t tri, int x, int y,
                                        const float* dec, const float* thr, const uint32_t* lvl /* [3][kMaxMipLevels] */)
 {
@@ -1003,9 +1054,15 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
 #pragma unroll
     for (int k = 0; k < 3; ++k) { wp[k] = fmaf(p2, w2[k], fmaf(p1, w1[k], p0 * w0[k])); N[k] = fmaf(p2, n2[k], fmaf(p1, n1[k], p0 * n0[k])); }
     float alb[3], met[1], rgh[1], rgb[3];
-    sample_texture<3>(p.albedo, lvl, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
-    sample_texture<1>(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, met);
-    sample_texture<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+    if constexpr (ANISO) {
+        sample_texture_aniso<3>(p.albedo, lvl, p.max_aniso, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
+        sample_texture_aniso<1>(p.metallic, lvl + kMaxMipLevels, p.max_aniso, u, v, dudx, dvdx, dudy, dvdy, dec, met);
+        sample_texture_aniso<1>(p.roughness, lvl + 2 * kMaxMipLevels, p.max_aniso, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+    } else {
+        sample_texture<3>(p.albedo, lvl, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
+        sample_texture<1>(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, met);
+        sample_texture<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+    }
     fragment_main(wp, N, vx.cam, alb, met[0], rgh[0], rgb);
     const uint32_t R = (uint32_t)srgb_encode8(rgb[0] > 1.0f ? 1.0f : rgb[0], thr);
     const uint32_t G = (uint32_t)srgb_encode8(rgb[1] > 1.0f ? 1.0f : rgb[1], thr);
@@ -1013,7 +1070,7 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     return B | (G << 8) | (R << 16) | (255u << 24);
 }
 
-template <int S, bool DIRTY = false, bool EXACT = false>
+template <int S, bool DIRTY = false, bool EXACT = false, bool ANISO = false>
 __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
 {
     __shared__ float s_dec[256];
@@ -1058,7 +1115,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
             for (int k = 0; k < s; ++k) if (k == prev) c = col[k];
             col[s] = c;
         } else {
-            col[s] = shade_pixel<EXACT>(p, vx, sv, ids[s], x, y, s_dec, s_thr, s_lvl);
+            col[s] = shade_pixel<EXACT, ANISO>(p, vx, sv, ids[s], x, y, s_dec, s_thr, s_lvl);
         }
     }
     uint32_t outc;
@@ -1278,6 +1335,12 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
     p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.dirty = f.dirty;
     const dim3 grid(div_up((uint32_t)f.g.rw, 32), div_up((uint32_t)f.g.rh, 8), f.n_views), block(32, 8);
     const bool dirty = f.dirty.flags != nullptr;   // the grid is the dirty map's block grid
+    p.max_aniso = f.max_anisotropy;
+    if (f.max_anisotropy > 1.0f && dirty && f.exact_vertices) {   // the anisotropic variant comes with the other two
+        if (f.g.samples == 1) fragment_kernel<1, true, true, true><<<grid, block, 0, st>>>(p);
+        else fragment_kernel<4, true, true, true><<<grid, block, 0, st>>>(p);
+        return;
+    }
     if (f.g.samples == 1) {
         if (dirty && f.exact_vertices) fragment_kernel<1, true, true><<<grid, block, 0, st>>>(p);
         else if (dirty) fragment_kernel<1, true, false><<<grid, block, 0, st>>>(p);

@@ -19,6 +19,7 @@ struct FragLaunch {
     uint32_t view0, n_views;
     DirtyMap dirty;            // flags == null: every block is shaded from the visibility buffer
     bool exact_vertices;       // recompute window-space vertices with the vertex stage's exact arithmetic
+    float max_anisotropy;      // > 1 (together with dirty + exact_vertices): the sampler's anisotropic footprint is applied
 };
 
 void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz);
