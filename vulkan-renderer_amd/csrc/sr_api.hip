@@ -564,18 +564,21 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
     if (e == hipSuccess && (dev->variants & kVariantFusedGeometry)) e = hipMalloc(&m->d_pos4, nv * 16);
     if (e != hipSuccess) { (void)hipFree(m->d_aos); (void)hipFree(m->px); (void)hipFree(m->d_idx); (void)hipFree(m->d_pos4); delete m; SR_HIP(e); }
     m->py = m->px + nv; m->pz = m->py + nv;
-    if (n_vertices) SR_HIP(hipMemcpyAsync(m->d_aos, vertices, (size_t)n_vertices * 32, hipMemcpyHostToDevice, dev->stream));
-    if (n_tris) SR_HIP(hipMemcpyAsync(m->d_idx, indices, (size_t)n_tris * 12, hipMemcpyHostToDevice, dev->stream));
-    launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
-    if (m->d_pos4) launch_pack_positions(dev->stream, m->d_aos, n_vertices, m->d_pos4);
-    if ((dev->variants & kVariantClusterCull) && n_tris) {
+    if (n_vertices) e = hipMemcpyAsync(m->d_aos, vertices, (size_t)n_vertices * 32, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess && n_tris) e = hipMemcpyAsync(m->d_idx, indices, (size_t)n_tris * 12, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) {
+        launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
+        if (m->d_pos4) launch_pack_positions(dev->stream, m->d_aos, n_vertices, m->d_pos4);
+    }
+    if (e == hipSuccess && (dev->variants & kVariantClusterCull) && n_tris) {
         const std::vector<ClusterRec> recs = build_clusters((const float*)vertices, indices, n_tris);
         m->n_clusters = (uint32_t)recs.size();
-        SR_HIP(hipMalloc((void**)&m->d_clusters, recs.size() * sizeof(ClusterRec)));
-        SR_HIP(hipMemcpy(m->d_clusters, recs.data(), recs.size() * sizeof(ClusterRec), hipMemcpyHostToDevice));
+        e = hipMalloc((void**)&m->d_clusters, recs.size() * sizeof(ClusterRec));
+        if (e == hipSuccess) e = hipMemcpy(m->d_clusters, recs.data(), recs.size() * sizeof(ClusterRec), hipMemcpyHostToDevice);
     }
-    SR_HIP(hipGetLastError());
-    SR_HIP(hipStreamSynchronize(dev->stream));   // uploaded on return, like the reference's blocking staging copy
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);   // uploaded on return, like the reference's blocking staging copy
+    if (e != hipSuccess) { (void)sr_mesh_destroy(dev, m); SR_HIP(e); }
     *out = m;
     return SR_OK;
 }
@@ -613,12 +616,13 @@ int sr_texture_create_rgba8_srgb(sr_device dev, const void* rgba8, int width, in
     if (sampler) t->samp = *sampler; else sr_sampler_default(&t->samp);
     hipError_t e = hipMalloc((void**)&t->d_chain, off * 4);
     if (e != hipSuccess) { delete t; SR_HIP(e); }
-    SR_HIP(hipMemcpyAsync(t->d_chain, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice, dev->stream));
-    for (int l = 1; l < levels; ++l)
+    e = hipMemcpyAsync(t->d_chain, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice, dev->stream);
+    for (int l = 1; l < levels && e == hipSuccess; ++l)
         launch_mip_blit(dev->stream, t->d_chain + t->level_off[l - 1], std::max(width >> (l - 1), 1), std::max(height >> (l - 1), 1),
                         t->d_chain + t->level_off[l], std::max(width >> l, 1), std::max(height >> l, 1), dev->d_decode, dev->d_thresh);
-    SR_HIP(hipGetLastError());
-    SR_HIP(hipStreamSynchronize(dev->stream));
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    if (e != hipSuccess) { (void)hipFree(t->d_chain); delete t; SR_HIP(e); }
     *out = t;
     return SR_OK;
 }
