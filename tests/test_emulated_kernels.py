@@ -53,7 +53,7 @@ def test_gpu_parity_suite_on_emulated_kernels():
 
 
 VARIANTS = ["fused_geometry", "dirty_blocks,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
-            "cluster_cull,sparse_tail,dirty_blocks,exact_shading", "anisotropic"]
+            "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512", "anisotropic"]
 
 
 def test_pipeline_variants_give_the_same_frames():

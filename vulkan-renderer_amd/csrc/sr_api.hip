@@ -64,6 +64,8 @@ enum : unsigned {
     kVariantClusterCull = 1u << 5,     // "cluster_cull": skip 64-triangle clusters that provably draw nothing (sr_device.h; implies fused_geometry)
     kVariantAnisotropic = 1u << 7,     // "anisotropic": the sampler's maxAnisotropy (src/texture.cpp:255-256) is applied, by the method the
                                        //                Vulkan specification spells out (implies dirty_blocks, exact_shading, fused_geometry)
+    kVariantRaster512 = 1u << 8,       // "raster_512": the 4-sample tile kernel runs 512 work-items per 32x32 tile; at 1024 it is capped at
+                                       //               128 registers and spills 500 bytes per work-item
     kVariantClusterVerify = 1u << 6,   // "cluster_cull_verify": evaluate the cluster test but skip nothing; count what skipped clusters
                                        //                        would have drawn into sr_draw_stats.cull_violations (for tests)
 };
@@ -81,6 +83,7 @@ unsigned parse_variants(const char* text)
         if (name == "fused_geometry") v |= kVariantFusedGeometry;
         if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "exact_shading") v |= kVariantExactShading;
+        if (name == "raster_512") v |= kVariantRaster512;
         if (name == "anisotropic") v |= kVariantAnisotropic | kVariantExactShading | kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "cluster_cull") v |= kVariantClusterCull | kVariantFusedGeometry;
         if (name == "cluster_cull_verify") v |= kVariantClusterVerify | kVariantClusterCull | kVariantFusedGeometry;
@@ -422,7 +425,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
             if (ev) SR_HIP(hipEventRecord(ev[5], st));
             launch_fill(st, g, b, m->n_tris, nv);
             if (ev) SR_HIP(hipEventRecord(ev[6], st));
-            launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty);
+            launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty, (dev->variants & kVariantRaster512) != 0);
         }
         if (ev) SR_HIP(hipEventRecord(ev[7], st));
         FragLaunch f{};

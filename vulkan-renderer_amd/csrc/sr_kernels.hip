@@ -1307,13 +1307,14 @@ static void launch_raster_config(hipStream_t st, dim3 grid, const uint32_t* idx,
 }
 
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                   uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty)
+                   uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty, bool half_workgroup)
 {
     if (!n_views) return;
     const dim3 grid((uint32_t)(g.tiles_x * g.tiles_y), n_views);
     unsigned long long* v = (unsigned long long*)vis;
     if (g.samples == 1 && g.tile_log2 == 6) launch_raster_config<6, 1, 1024>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
     else if (g.samples == 1 && g.tile_log2 == 5) launch_raster_config<5, 1, 256>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
+    else if (g.samples == 4 && g.tile_log2 == 5 && half_workgroup) launch_raster_config<5, 4, 512>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
     else if (g.samples == 4 && g.tile_log2 == 5) launch_raster_config<5, 4, 1024>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
     else if (g.samples == 4 && g.tile_log2 == 4) launch_raster_config<4, 4, 256>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
 }

@@ -46,7 +46,8 @@ void launch_begin_pass_dirty(hipStream_t st, uint64_t* vis, const FrameGeom& g, 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters);
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views);
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                   uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty = DirtyMap{nullptr, 0, 0});
+                   uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty = DirtyMap{nullptr, 0, 0},
+                   bool half_workgroup = false /* 4-sample 32x32 tiles with 512 work-items instead of 1024 (no register spills) */);
 bool raster_config_supported(int samples, int tile_log2);
 uint32_t setup_block_triangles();   // triangles handled by one set-up block
 uint32_t setup_block_records();     // size of the record segment one set-up block owns
