@@ -250,6 +250,38 @@ def test_multi_view_batch_matches_single_views(sr, oracle, device):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
+def test_view_batch_split_into_passes(sr, oracle, device, samples):
+    """BASELINE config 5 in small: more views than the per-view scratch budget holds at once, so one draw
+    runs as several passes (here 1 MiB: a handful of views per pass).  Every view equals the oracle's, and
+    the counters add up over the passes."""
+    import os
+    verts, idx = sr.scene.uv_sphere(40, 30)
+    n_views, W, H = 13, 200, 120
+    ubos = sr.scene.orbit_ubos(n_views, W, H)
+    images = sr.scene.material_textures(32)
+    os.environ["SR_SCRATCH_MIB"] = "1"
+    try:
+        dev = sr.Device(0)
+    finally:
+        del os.environ["SR_SCRATCH_MIB"]
+    try:
+        got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples)
+        for k in range(n_views):
+            ref = oracle.draw(ubos[k], verts, idx, images, W, H, samples)
+            _check_view(got[k], ref)
+        st = got[0]["stats"]
+        assert st["triangles"] == n_views * (idx.size // 3) and st["pixels"] == n_views * W * H
+        assert st["shaded_pixels"] == sum(int((g["tri"] != sr.NO_TRIANGLE).any(axis=-1).sum()) for g in got)
+        # the same batch in one pass (default budget) reports the same work
+        one = util.gpu_render(sr, device, verts, idx, images, ubos, W, H, samples)
+        assert {k: v for k, v in one[0]["stats"].items()} == st
+        for a, b in zip(got, one):
+            assert np.array_equal(a["vis"], b["vis"]) and np.array_equal(a["bgra"], b["bgra"])
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("samples", [1, 4])
 def test_screen_split_is_partition_independent(sr, oracle, device, samples):
     """Sort-first building block: a target restricted to a rectangle stores exactly the crop of the
     full frame, for rectangles that cut through tiles and pixels quads."""

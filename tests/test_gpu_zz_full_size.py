@@ -185,3 +185,62 @@ def test_windows_of_the_frame_match_the_oracle(sr, oracle, frame):
         # window alone is held to 99 %; it is 0.3 % of the frame.
         assert frac >= (0.99 if name == "pole" else 0.999), f"{name}: only {frac:.5f} of the pixels within 1 LSB (worst {worst})"
         assert (got_tri != sr.NO_TRIANGLE).any(), f"{name}: window misses the sphere"
+
+
+def test_config2_64_views_in_one_draw(sr, oracle, device):
+    """BASELINE config 2: the reference-sized mesh (88 x 88 sphere) at 1920x1080, 64 orbit cameras in one
+    draw.  Eight of the views are checked against the oracle, all of them for a plausible silhouette."""
+    W, H = (192, 108) if SMALL else (1920, 1080)
+    verts, idx = sr.scene.uv_sphere(88, 88)
+    images = sr.scene.material_textures(64 if SMALL else 1024)
+    ubos = sr.scene.orbit_ubos(64, W, H)
+    mesh = sr.create_mesh_from_data(device, verts, idx)
+    tex = [sr.create_texture(device, im) for im in images]
+    tgt = sr.RenderTarget(device, W, H, samples=1, n_views=64)
+    try:
+        sr.draw(device, tgt, mesh, ubos, tex)
+        chains = [(oracle.build_mip_chain(im), im.shape[1], im.shape[0]) for im in images]
+        expected_area = math.pi * ((H / 2) * (1.0 / math.sqrt(11.0)) / math.tan(math.radians(22.5))) ** 2
+        for v in range(64):
+            tri = tgt.read_triangle_ids(v)[..., 0]
+            covered = int((tri != sr.NO_TRIANGLE).sum())
+            assert abs(covered - expected_area) < 0.03 * expected_area, (v, covered, expected_area)   # a faceted sphere, every camera at the same distance
+            if v % 8 == 3:
+                ref = oracle.draw(ubos[v], verts, idx, chains, W, H, threads=8)
+                assert np.array_equal(tri, ref["tri"][..., 0]) and np.array_equal(tgt.read_depth(v).view(np.uint32), ref["depth"].view(np.uint32)), v
+                frac, worst = util.color_match_fraction(tgt.read_color(v), ref["bgra"], tol=1)
+                assert frac >= 0.999, (v, frac, worst)
+        st = tgt.stats()
+        assert st["triangles"] == 64 * (idx.size // 3) and st["pixels"] == 64 * W * H
+    finally:
+        tgt.destroy()
+        mesh.destroy()
+        for t in tex:
+            t.destroy()
+
+
+def test_config4_sort_first_bands_of_an_8k_frame(sr, device, frame):
+    """BASELINE config 4: the 10 M-triangle scene at 7680x4320 cut into the eight horizontal bands a
+    sort-first split over eight GPUs would use (softraster.distributed.split_bands), each band drawn by its
+    own target as a rank would: together they are exactly the frame drawn in one piece."""
+    from softraster import distributed as d
+    W, H = (960, 540) if SMALL else (7680, 4320)
+    ubo = sr.scene.default_camera_ubo(W, H)
+    whole = sr.RenderTarget(device, W, H, samples=1, n_views=1)
+    try:
+        sr.draw(device, whole, frame["mesh"], ubo, frame["tex"])
+        vis, bgra = whole.read_visibility(0), whole.read_color(0)
+    finally:
+        whole.destroy()
+    assert (vis[..., 0] & 0xFFFFFFFF != sr.NO_TRIANGLE).any()
+    bands = d.split_bands(W, H, 8)
+    assert sum(b[3] for b in bands) == H
+    for band in bands:
+        tgt = sr.RenderTarget(device, W, H, samples=1, n_views=1, rect=band)
+        try:
+            sr.draw(device, tgt, frame["mesh"], ubo, frame["tex"])
+            rows = slice(band[1], band[1] + band[3])
+            assert np.array_equal(tgt.read_visibility(0), vis[rows]), band
+            assert np.array_equal(tgt.read_color(0), bgra[rows]), band
+        finally:
+            tgt.destroy()
