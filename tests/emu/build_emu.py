@@ -57,5 +57,23 @@ def build(force: bool = False, opt: str = "-O1") -> str:
     return LIB
 
 
+def build_sanitized(force: bool = False) -> str:
+    """The same sources plus tests/emu/asan_scenes.cpp as one executable under AddressSanitizer and
+    UndefinedBehaviorSanitizer.  Stack instrumentation is off (work-items run on hand-made stacks);
+    globals -- which is what __shared__ arrays become here -- and the heap are fenced."""
+    build(force)   # writes the rewritten sources
+    exe = os.path.join(BUILD, "asan_scenes")
+    deps = [LIB, os.path.join(HERE, "asan_scenes.cpp")]
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) >= newest(deps):
+        return exe
+    units = [os.path.join(BUILD, f.replace(".hip", "_emu.cpp")) for f in SOURCES]
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-march=x86-64-v3", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize=alignment",
+           "--param", "asan-stack=0", "-static-libasan", "-static-libubsan", "-Wno-unknown-pragmas", "-Wno-subobject-linkage", "-U_FORTIFY_SOURCE",
+           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), *units, os.path.join(CSRC, "sr_assets.cpp"),
+           os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "asan_scenes.cpp"), "-lz", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

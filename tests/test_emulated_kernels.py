@@ -132,6 +132,22 @@ np.save({str(tmp_path / 'py.npy')!r}, tgt.read_color(0))
     assert np.array_equal(rgb, bgra[..., [2, 1, 0]])
 
 
+def test_scene_driver_under_address_and_ub_sanitizers():
+    """tests/emu/asan_scenes.cpp: spheres and triangle soups through the C ABI, 1 and 4 samples, several
+    views, restricted rectangles, every target drawn twice -- kernels and host code under AddressSanitizer
+    (workgroup-local arrays and the heap) and UndefinedBehaviorSanitizer, for the default pipeline and for
+    the variants.  Any report fails the run."""
+    build_emulation_library()
+    import build_emu
+    exe = build_emu.build_sanitized()
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    runs = [(v, subprocess.Popen([exe], env=dict(env, SR_VARIANT=v), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+            for v in ("", "cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading,raster_512", "anisotropic,sparse_tail_force,cluster_cull")]
+    for v, proc in runs:
+        out, _ = proc.communicate(timeout=1200)
+        assert proc.returncode == 0 and "ok: 32 draws" in out and "runtime error" not in out and "AddressSanitizer" not in out, f"variant '{v}':\n{out[-3000:]}"
+
+
 def test_out_of_range_access_is_reported(tmp_path):
     """The fence works: a kernel launched with a block shape its indexing does not expect is caught."""
     src = os.path.join(ROOT, "tests", "emu", "selftest_fault.cpp")
