@@ -75,9 +75,9 @@ def test_full_size_frame_on_emulated_kernels():
     pipeline and on the combination of all variants."""
     build_emulation_library()
     what = os.path.join("tests", "test_gpu_zz_full_size.py")
-    # (the 64-view and 8K configurations of that file run at reduced size in the suites above: at full size they take minutes here)
-    runs = [start_gpu_suite_emulated(what=what, select="not config", SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1"),
-            start_gpu_suite_emulated(what=what, select="not config", SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1",
+    # (the 64-view, 8K and 16K configurations of that file run at reduced size in the suites above: at full size they take minutes here)
+    runs = [start_gpu_suite_emulated(what=what, select="not config and not largest", SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1"),
+            start_gpu_suite_emulated(what=what, select="not config and not largest", SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1",
                                      SR_VARIANT="cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading")]
     for r in runs:
         finish(r)

@@ -244,3 +244,45 @@ def test_config4_sort_first_bands_of_an_8k_frame(sr, device, frame):
             assert np.array_equal(tgt.read_color(0), bgra[rows]), band
         finally:
             tgt.destroy()
+
+
+def test_largest_frame(sr, oracle, device):
+    """The largest frame a target accepts, 16384 x 16384 (256 x 256 tiles, 14-bit pixel coordinates): the
+    silhouette is the closed-form disc, and three windows -- frame centre, the last tile column at the
+    disc's right rim, the far corner -- equal the oracle's."""
+    N = 1024 if SMALL else 16384
+    verts, idx = sr.scene.uv_sphere(88, 88)
+    images = sr.scene.material_textures(64)
+    # a wide lens (100 degrees) is not needed: move the camera close so that the sphere reaches the frame's edge columns
+    eye = (1.45, 1.45, 1.45)
+    ubo = sr.scene.default_camera_ubo(N, N, eye=eye)
+    mesh = sr.create_mesh_from_data(device, verts, idx)
+    tex = [sr.create_texture(device, im) for im in images]
+    tgt = sr.RenderTarget(device, N, N, samples=1, n_views=1)
+    try:
+        sr.draw(device, tgt, mesh, ubo, tex)
+        tri = tgt.read_triangle_ids(0)[..., 0]
+        bgra = tgt.read_color(0)
+        st = tgt.stats()
+        covered = tri != sr.NO_TRIANGLE
+        assert st["pixels"] == N * N and st["shaded_pixels"] == int(covered.sum())
+        d = math.sqrt(3 * 1.45 ** 2)
+        radius = (N / 2) * (1.0 / math.sqrt(d * d - 1.0)) / math.tan(math.radians(22.5))
+        assert radius > N / 2, "the test wants the sphere to run over the frame's edges"
+        assert covered[N // 2, :].all() and covered[:, N // 2].all()        # the central row and column are inside the disc
+        assert not covered[0, 0] and not covered[N - 1, N - 1]               # the corners are outside
+        w = 64 if SMALL else 192
+        chains = [(oracle.build_mip_chain(im), im.shape[1], im.shape[0]) for im in images]
+        # where the silhouette crosses the last column: x = N-1, |y - N/2| = sqrt(radius^2 - (N/2)^2)
+        y_cross = int(N / 2 - math.sqrt(radius * radius - (N / 2) ** 2))
+        for name, (x, y) in {"centre": (N // 2 - w // 2, N // 2 - w // 2), "last column": (N - w, max(0, y_cross - w // 2)), "corner": (N - w, N - w)}.items():
+            ref = oracle.draw(ubo, verts, idx, chains, N, N, rect=(x, y, w, w), threads=8)
+            assert np.array_equal(tri[y:y + w, x:x + w], ref["tri"][..., 0]), name
+            frac, worst = util.color_match_fraction(bgra[y:y + w, x:x + w], ref["bgra"], tol=1)
+            assert frac >= 0.999, (name, frac, worst)
+        assert (tri[y_cross - 2:y_cross + 2, N - 8:] != sr.NO_TRIANGLE).any() and (tri[max(0, y_cross - w // 2):y_cross + w // 2, N - w:] == sr.NO_TRIANGLE).any()
+    finally:
+        tgt.destroy()
+        mesh.destroy()
+        for t in tex:
+            t.destroy()
