@@ -27,16 +27,18 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 WORKLOADS = {
-    # name: (width, height, sphere X, sphere Y, albedo size, other maps size)
-    "c3_4k_10Mtri": (3840, 2160, 2500, 2000, 4096, 2048),
-    "small_1080p_124ktri": (1920, 1080, 250, 248, 1024, 512),   # for quick checks only
+    # name: (width, height, sphere X, sphere Y, albedo size, other maps size, samples, views per GPU)
+    "c3_4k_10Mtri": (3840, 2160, 2500, 2000, 4096, 2048, 1, 1),          # the headline: BASELINE config 3
+    "small_1080p_124ktri": (1920, 1080, 250, 248, 1024, 512, 1, 1),       # for quick checks only
+    "c1_800x600_msaa4": (800, 600, 88, 88, 2048, 2048, 4, 1),             # the reference's own frame: large triangles, 4 samples
+    "c2_1080p_64views": (1920, 1080, 88, 88, 2048, 2048, 1, 64),          # BASELINE config 2: one draw of 64 cameras
 }
 
 
 def kernel_bytes(st, n_tiles):
     """Algorithmic (compulsory) HBM bytes of each kernel for one frame: every array counted once per
     kernel that must touch it, caches assumed perfect inside a kernel.  st: counters of the draw."""
-    V, T, P, S = st["vertices"], st["triangles"], st["pixels"], 1
+    V, T, P, S = st["vertices"], st["triangles"], st["pixels"], st.get("samples", 1)
     B, R, Fd, F, Pv = st["triangles_binned"], st["tile_refs"], st["triangles_direct"], st["visible_triangles"], st["shaded_pixels"]
     X = Pv * 3 * 1.33                       # unique texels over the three maps (model)
     direct_samples = Pv * S * (Fd / max(F, 1)) if F else 0
@@ -56,7 +58,7 @@ def frame_bytes_reference_model(st):
     """The per-frame figure of the measurement plan this benchmark follows: vertex V*28; set-up/bin
     T*12 + V*16 + R*4; raster R*4 + R*12 + V*16 + P*S*8; fragment P*S*8 + F*108 + X*4 + P*4, with R =
     surviving (triangle, tile) references (here: tile references + directly resolved triangles)."""
-    V, T, P, S = st["vertices"], st["triangles"], st["pixels"], 1
+    V, T, P, S = st["vertices"], st["triangles"], st["pixels"], st.get("samples", 1)
     R = st["tile_refs"] + st["triangles_direct"]
     F, Pv = st["visible_triangles"], st["shaded_pixels"]
     X = Pv * 3 * 1.33
@@ -147,16 +149,18 @@ def main():
     import softraster as sr
     if args.mode == "sortfirst":
         return sort_first(args, sr, rank, local_rank, world)
-    W, H, SX, SY, alb_size, map_size = WORKLOADS[args.workload]
+    W, H, SX, SY, alb_size, map_size, samples, views = WORKLOADS[args.workload]
     verts, idx = sr.scene.uv_sphere(SX, SY)
     images = [sr.scene.albedo_pattern(alb_size), None, sr.scene.gray_map(map_size, map_size, 0, 254), sr.scene.gray_map(map_size, map_size, 72, 255)]
     # rank r draws view r of a `world`-camera orbit; view 0 is the reference's default camera
     ubo = sr.scene.default_camera_ubo(W, H, eye=sr.scene.orbit_eye(rank, max(world, 1)) if world > 1 else (2.0, 2.0, 2.0))
+    if views > 1:   # a batch: this rank's share of a world*views-camera orbit
+        ubo = sr.scene.orbit_ubos(views, W, H, first=rank * views, total=world * views)
 
     dev = sr.Device(local_rank)
     mesh = sr.create_mesh_from_data(dev, verts, idx)
     tex = [sr.create_texture(dev, im) if im is not None else None for im in images]
-    tgt = sr.RenderTarget(dev, W, H, samples=1, n_views=1)
+    tgt = sr.RenderTarget(dev, W, H, samples=samples, n_views=views)
 
     def barrier():
         dev.synchronize()
@@ -167,6 +171,7 @@ def main():
     for _ in range(max(args.warmup, 1)):   # the first draw also sizes the tile reference list
         sr.draw(dev, tgt, mesh, ubo, tex)
     stats = tgt.stats()
+    stats["samples"] = samples
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -198,9 +203,10 @@ def main():
         T = stats["triangles"]; V = stats["vertices"]; R = stats["tile_refs"]; F = stats["visible_triangles"]
         P = stats["pixels"]; Pv = stats["shaded_pixels"]; surv = stats["triangles_binned"]
         ms_per_step = elapsed / args.steps * 1e3
-        frames_per_s = world * args.steps / elapsed
-        mtris = T * frames_per_s / 1e6
-        n_tiles = ((W + 63) // 64) * ((H + 63) // 64)
+        frames_per_s = world * views * args.steps / elapsed
+        mtris = (T // views) * frames_per_s / 1e6
+        tile = 64 if samples == 1 else 32
+        n_tiles = ((W + tile - 1) // tile) * ((H + tile - 1) // tile) * views
         by = kernel_bytes(stats, n_tiles)
         kernels = {k: stage_ms[k + "_ms"] for k in ("clear", "vertex", "setup", "bin", "scan", "fill", "raster", "fragment")}
         dom = max(kernels, key=kernels.get)
@@ -218,12 +224,12 @@ def main():
             "value": round(mtris, 2), "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "width": W, "height": H, "triangles": T, "vertices": V, "samples": 1,
-                       "views_per_gpu": 1, "sharding": "by view (no collective)" if world > 1 else "single GPU",
+            "config": {"workload": args.workload, "width": W, "height": H, "triangles": T // views, "vertices": V // views, "samples": samples,
+                       "views_per_gpu": views, "sharding": "by view (no collective)" if world > 1 else "single GPU",
                        "pipeline_variant": os.environ.get("SR_VARIANT", "") or "default"},
             "frames_per_s": round(frames_per_s, 2),
             "gpixels_shaded_per_s": round(shaded_total * args.steps / elapsed / 1e9, 4),
-            "counters": {"V": V, "T": T, "R": R, "F": F, "P": P, "Pv": Pv, "S": 1, "binned": surv, "direct": stats["triangles_direct"]},
+            "counters": {"V": V, "T": T, "R": R, "F": F, "P": P, "Pv": Pv, "S": samples, "binned": surv, "direct": stats["triangles_direct"]},
             "kernel_ms": {k: round(v, 4) for k, v in kernels.items()},
             "kernel_algorithmic_MB": {k: round(v / 1e6, 1) for k, v in by.items()},
             "frame_algorithmic_bytes": int(frame_bytes),
@@ -236,9 +242,9 @@ def main():
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             chains = [(oracle.build_mip_chain(im), im.shape[1], im.shape[0]) if im is not None else (np.zeros((1, 4), np.uint8), 1, 1) for im in images]
             tc = time.perf_counter()
-            oracle.draw(ubo, verts, idx, chains, W, H, 1, threads=threads)
+            oracle.draw(ubo if views == 1 else ubo[0], verts, idx, chains, W, H, samples, threads=threads)
             cpu_s = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": round(T / cpu_s / 1e6, 3), "unit": "Mtris/s", "cores": threads, "kind": "port",
+            out["cpu_baseline"] = {"value": round((T // views) / cpu_s / 1e6, 3), "unit": "Mtris/s", "cores": threads, "kind": "port",
                                    "sample": f"one full {W}x{H} frame of the same scene (mip chains prebuilt), {cpu_s:.2f} s"}
         print(json.dumps(out), flush=True)
 
