@@ -21,14 +21,16 @@ for v in "${VARIANTS[@]}"; do
     vv=$v; [ "$v" = "default" ] && vv=""
     tag=$(echo "$v" | tr ',' '+')
     CMD+="echo '== $v'; SR_VARIANT='$vv' timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/test_$tag.log 2>&1 || { grep -n -m1 -A30 '^=* FAILURES' gpurun_out/test_$tag.log; exit 1; }; tail -1 gpurun_out/test_$tag.log; "
-    CMD+="SR_VARIANT='$vv' timeout -k 10 300 python -u bench.py --steps 30 --no-cpu-baseline > gpurun_out/bench_$tag.log 2>&1 || { tail -5 gpurun_out/bench_$tag.log; exit 1; }; tail -1 gpurun_out/bench_$tag.log; "
+    for wl in c3_4k_10Mtri c1_800x600_msaa4 c2_1080p_64views; do   # the headline, then two scenes of large triangles (what a variant must not slow down)
+        CMD+="SR_VARIANT='$vv' timeout -k 10 300 python -u bench.py --workload $wl --steps 30 --no-cpu-baseline > gpurun_out/bench_${tag}_$wl.log 2>&1 || { tail -5 gpurun_out/bench_${tag}_$wl.log; exit 1; }; tail -1 gpurun_out/bench_${tag}_$wl.log; "
+    done
 done
 (timeout 1500 /usr/local/graft/bin/gpurun --timeout 1100 -- "$CMD") 2>&1 | grep -v "^\[gpurun\] \(sending\|merged\)" | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l)
-        print('   %-40s %8.1f Mtris/s  %.4f ms  hbm %.3f' % (d['config'].get('pipeline_variant'), d['value'], d['ms_per_step'], d['frame_hbm_fraction']))
+        print('   %-20s %-40s %8.1f Mtris/s  %.4f ms  hbm %.3f' % (d['config']['workload'], d['config'].get('pipeline_variant'), d['value'], d['ms_per_step'], d['frame_hbm_fraction']))
         print('   ', d['kernel_ms'])
     else:
         print(l.rstrip())
