@@ -1018,8 +1018,21 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     const float e1x = (float)(v1.X - v0.X), e1y = (float)(v1.Y - v0.Y);
     const float e2x = (float)(v2.X - v0.X), e2y = (float)(v2.Y - v0.Y);
     const float dx = (float)(x * kSubpix + kHalf - v0.X), dy = (float)(y * kSubpix + kHalf - v0.Y);
-    const float rA = frcp(e1x * e2y - e1y * e2x);
-    const float l1 = (dx * e2y - dy * e2x) * rA, l2 = (e1x * dy - e1y * dx) * rA, l0 = 1.0f - l1 - l2;
+    float rA, l0, l1, l2;
+    if constexpr (EXACT) {
+        // Each weight from its own cross product of the two opposite vertices seen from the pixel: its error is
+        // relative to its own size.  (The form below, l0 = 1 - l1 - l2 around vertex 0, loses l0 when vertex 0 is
+        // far away and close to the eye plane: its huge 1/w then multiplies the rounding error of l1 + l2.)
+        const int32_t px = x * kSubpix + kHalf, py = y * kSubpix + kHalf;
+        const float a0x = (float)(v0.X - px), a0y = (float)(v0.Y - py), a1x = (float)(v1.X - px), a1y = (float)(v1.Y - py);
+        const float a2x = (float)(v2.X - px), a2y = (float)(v2.Y - py);
+        const float E0 = a1x * a2y - a1y * a2x, E1 = a2x * a0y - a2y * a0x, E2 = a0x * a1y - a0y * a1x;
+        rA = frcp((E0 + E1) + E2);
+        l0 = E0 * rA; l1 = E1 * rA; l2 = E2 * rA;
+    } else {
+        rA = frcp(e1x * e2y - e1y * e2x);
+        l1 = (dx * e2y - dy * e2x) * rA; l2 = (e1x * dy - e1y * dx) * rA; l0 = 1.0f - l1 - l2;
+    }
     // gradients per pixel step (256 sub-pixels)
     const float s = (float)kSubpix * rA;
     const float l1x = e2y * s, l1y = -e2x * s, l2x = -e1y * s, l2y = e1x * s;
