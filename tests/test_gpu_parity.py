@@ -250,6 +250,31 @@ def test_multi_view_batch_matches_single_views(sr, oracle, device):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
+def test_tile_reference_list_grows_and_the_draw_is_repeated(sr, oracle, samples):
+    """The per-tile reference list is sized from earlier frames; a frame that needs more overflows it (the
+    overflowing references are dropped and counted, never written) and is drawn again with a larger list
+    when its target is next read.  Forced here with a list of 64 entries against thousands needed."""
+    import os
+    verts, idx = util.random_soup(300, 21, size=1.2)
+    W, H = 320, 200
+    ubos = sr.scene.orbit_ubos(2, W, H)
+    images = sr.scene.material_textures(32)
+    os.environ["SR_REF_CAPACITY"] = "64"
+    try:
+        dev = sr.Device(0)
+    finally:
+        del os.environ["SR_REF_CAPACITY"]
+    try:
+        for attempt in range(2):   # the second frame finds the list already large enough
+            got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples)
+            assert got[0]["stats"]["tile_refs"] > 64 or got[0]["stats"]["tile_refs"] == 0
+            for k in range(2):
+                _check_view(got[k], oracle.draw(ubos[k], verts, idx, images, W, H, samples))
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("samples", [1, 4])
 def test_view_batch_split_into_passes(sr, oracle, device, samples):
     """BASELINE config 5 in small: more views than the per-view scratch budget holds at once, so one draw
     runs as several passes (here 1 MiB: a handful of views per pass).  Every view equals the oracle's, and

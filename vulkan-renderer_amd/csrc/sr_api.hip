@@ -519,6 +519,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     SR_HIP(hipMemcpy(dev->d_thresh, thr, sizeof thr, hipMemcpyHostToDevice));
     if (const char* e = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(e);
     if (const char* e = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 30;
+    if (const char* e = std::getenv("SR_REF_CAPACITY")) dev->ref_capacity = (uint64_t)std::max(1, std::atoi(e));   // initial size of the tile reference list (tests: force the grow-and-redraw path)
     if (const char* e = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 20;   // small budgets: many passes per draw
     dev->variants = parse_variants(std::getenv("SR_VARIANT"));
     if (dev->variants & kVariantClusterVerify) SR_HIP(hipMalloc((void**)&dev->d_cull_violations, 4));
