@@ -274,6 +274,43 @@ def test_tile_reference_list_grows_and_the_draw_is_repeated(sr, oracle, samples)
         dev.close()
 
 
+def test_more_distinct_tiles_than_a_binning_block_can_hash(sr, oracle):
+    """One binning workgroup (1024 consecutive triangles) keeps its (triangle, tile) pairs in a 2048-slot hash
+    table.  1024 small triangles, each sitting on a different tile corner (so 4096 distinct pairs over
+    4096 distinct tiles), overflow it; the pairs that find no slot take the per-tile slow path.  16-pixel
+    tiles (SR_TILE_LOG2=4, 4 samples) keep the frame small."""
+    import os
+    W = H = 2048
+    T = 16
+    per_row = (W // T - 2) // 2
+    n = 1024
+    assert (n // per_row + 1) * 2 * T + 2 * T <= H
+    verts = np.zeros((n * 3, 8), np.float32)
+    for k in range(n):
+        cx, cy = T * (2 + 2 * (k % per_row)), T * (2 + 2 * (k // per_row))          # a tile corner, in pixels
+        pts = [(cx - 3.3, cy - 2.6), (cx - 2.1, cy + 3.7), (cx + 3.4, cy + 0.4)]     # counter-clockwise as displayed
+        for j, (x, y) in enumerate(pts):
+            verts[3 * k + j, 0:3] = (2.0 * x / W - 1.0, 1.0 - 2.0 * y / H, 0.3 + 0.0001 * k)
+            verts[3 * k + j, 5] = 1.0
+            verts[3 * k + j, 6:8] = (x / 7.0, y / 5.0)
+    idx = np.arange(n * 3, dtype=np.uint32)
+    eye = np.eye(4, dtype=np.float32)
+    ubo = sr.scene.make_ubo(eye, eye, eye, (0.0, 0.0, 5.0))
+    images = sr.scene.material_textures(16)
+    os.environ["SR_TILE_LOG2"] = "4"
+    try:
+        dev = sr.Device(0)
+    finally:
+        del os.environ["SR_TILE_LOG2"]
+    try:
+        got = util.gpu_render(sr, dev, verts, idx, images, ubo, W, H, 4)[0]
+        st = got["stats"]
+        assert st["triangles_binned"] == n and (st["tile_refs"] == 4 * n or st["tile_refs"] == 0), st   # every triangle straddles 2 x 2 tiles
+        _check_view(got, oracle.draw(ubo, verts, idx, images, W, H, 4, threads=4))
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("samples", [1, 4])
 def test_view_batch_split_into_passes(sr, oracle, device, samples):
     """BASELINE config 5 in small: more views than the per-view scratch budget holds at once, so one draw
