@@ -1,0 +1,22 @@
+// TEST INFRASTRUCTURE ONLY: runs the PNG and glTF readers (vulkan-renderer_amd/csrc/sr_assets.cpp) over the
+// files named on the command line under AddressSanitizer / UndefinedBehaviorSanitizer.  The files are
+// mutated copies of valid ones; the readers may refuse them, they may not read or write out of bounds.
+#include "sr_assets.h"
+
+#include <cstdio>
+#include <cstring>
+
+int main(int argc, char** argv)
+{
+    int accepted = 0, refused = 0;
+    for (int i = 1; i < argc; ++i) {
+        std::string err;
+        const size_t n = std::strlen(argv[i]);
+        bool ok;
+        if (n > 4 && !std::strcmp(argv[i] + n - 4, ".png")) { sr_assets::Image img; ok = sr_assets::load_image(argv[i], img, err); }
+        else { std::vector<sr_assets::HostMesh> meshes; ok = sr_assets::load_model(argv[i], meshes, err); }
+        ok ? ++accepted : ++refused;
+    }
+    std::printf("accepted %d refused %d\n", accepted, refused);
+    return 0;
+}

@@ -164,6 +164,14 @@ def test_differential_fuzzing_against_the_oracle():
         assert proc.returncode == 0 and "ok: seeds" in out, f"variant '{v}':\n{out[-3000:]}"
 
 
+def test_file_readers_survive_mutated_files():
+    """tests/emu/fuzz_files.py and fuzz_png.py, a short run each: the PNG and glTF readers under
+    AddressSanitizer / UndefinedBehaviorSanitizer on mutated files."""
+    for script in ("fuzz_files.py", "fuzz_png.py"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", script), "3", "6"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok "), r.stdout[-3000:]
+
+
 def test_out_of_range_access_is_reported(tmp_path):
     """The fence works: a kernel launched with a block shape its indexing does not expect is caught."""
     src = os.path.join(ROOT, "tests", "emu", "selftest_fault.cpp")

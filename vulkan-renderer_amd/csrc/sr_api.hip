@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -669,7 +670,9 @@ int sr_image_read_file(const char* path, void** rgba8_out, int* width, int* heig
     *rgba8_out = nullptr;
     sr_assets::Image img;
     std::string err;
-    if (!sr_assets::load_image(path, img, err)) return fail(SR_ERR_FILE, err);
+    try {
+        if (!sr_assets::load_image(path, img, err)) return fail(SR_ERR_FILE, err);
+    } catch (const std::exception& e) { return fail(SR_ERR_OUT_OF_MEMORY, std::string("reading ") + path + ": " + e.what()); }
     void* p = std::malloc(img.rgba.size());
     if (!p) return fail(SR_ERR_OUT_OF_MEMORY, "host allocation failed");
     std::memcpy(p, img.rgba.data(), img.rgba.size());
@@ -685,7 +688,9 @@ int sr_texture_create_from_file(sr_device dev, const char* path, const sr_sample
     *out = nullptr;
     sr_assets::Image img;
     std::string err;
-    if (!sr_assets::load_image(path, img, err)) return fail(SR_ERR_FILE, "failed to load texture image: " + err);   // src/texture.cpp:281-284
+    try {
+        if (!sr_assets::load_image(path, img, err)) return fail(SR_ERR_FILE, "failed to load texture image: " + err);   // src/texture.cpp:281-284
+    } catch (const std::exception& e) { return fail(SR_ERR_OUT_OF_MEMORY, std::string("reading ") + path + ": " + e.what()); }
     return sr_texture_create_rgba8_srgb(dev, img.rgba.data(), img.width, img.height, sampler, out);
 }
 
@@ -695,7 +700,9 @@ int sr_model_read_file(const char* path, sr_model* out)
     *out = nullptr;
     sr_model_t* m = new sr_model_t();
     std::string err;
-    if (!sr_assets::load_model(path, m->host, err)) { delete m; return fail(SR_ERR_FILE, err); }
+    try {
+        if (!sr_assets::load_model(path, m->host, err)) { delete m; return fail(SR_ERR_FILE, err); }
+    } catch (const std::exception& e) { delete m; return fail(SR_ERR_OUT_OF_MEMORY, std::string("reading ") + path + ": " + e.what()); }
     *out = m;
     return SR_OK;
 }

@@ -88,6 +88,9 @@ bool decode_png(const uint8_t* data, size_t size, Image& img, std::string& err)
     if (!depth_ok) { err = "bit depth not allowed for this PNG colour type"; return false; }
     if (ctype == 3 && plte.size() < 3) { err = "palette PNG without PLTE"; return false; }
     const size_t bits_pp = (size_t)channels * depth, stride = ((size_t)w * bits_pp + 7) / 8, bpp = std::max<size_t>(bits_pp / 8, 1);
+    // deflate cannot expand by more than about 1032:1: a header that promises more than the data can hold is refused
+    // before anything of that size is allocated
+    if ((stride + 1) * (size_t)h > idat.size() * 1032 + 65536) { err = "PNG image data is too short for the size in its header"; return false; }
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf raw_len = (uLongf)raw.size();
     const int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
@@ -338,6 +341,7 @@ struct Gltf {
         const bool normalized = a->get("normalized") && a->get("normalized")->kind == Json::Bool && a->get("normalized")->b;
         const Json* bvi = a->get("bufferView");
         if (!bvi) {   // all zeros by definition
+            if (count > ((size_t)1 << 26)) return fail("glTF: accessor without a buffer view is unreasonably large");   // nothing in the file backs this size
             if (floats) floats->assign(count * want_components, 0.0f);
             if (ints) ints->assign(count, 0u);
             return true;
