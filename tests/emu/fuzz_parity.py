@@ -65,6 +65,8 @@ def main():
         rng = np.random.default_rng(seed)
         verts, idx = random_scene(rng)
         W, H = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+        if seed % 16 == 5:   # now and then a frame of many tiles
+            W, H = int(rng.integers(600, 1500)), int(rng.integers(400, 900))
         samples = int(rng.choice([1, 4]))
         n_views = int(rng.integers(1, 4))
         rect = None

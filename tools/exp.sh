@@ -1,16 +1,23 @@
 #!/bin/bash
-# usage: tools/exp.sh 'python-replace-snippet'  -- applies a temporary edit to sr_kernels.hip, builds, benches C3, restores
-cd /root/repo
-cp vulkan-renderer_amd/csrc/sr_kernels.hip /tmp/sr_kernels.exp.bak
-python - "$1" "$2" <<'PY'
+# usage: tools/exp.sh 'old text' 'new text'
+# Applies a temporary edit to sr_kernels.hip, builds, checks the edited kernels on the CPU execution harness
+# (tests/emu: an indexing mistake fails there instead of faulting a GPU), benches C3 on the GPU box, then
+# restores the source and rebuilds -- whatever happened in between.
+cd /root/repo || exit 1
+SRC=vulkan-renderer_amd/csrc/sr_kernels.hip
+cp $SRC /tmp/sr_kernels.exp.bak
+restore() { cp /tmp/sr_kernels.exp.bak $SRC; python -c "import __graft_entry__ as g; g.build()"; }
+trap restore EXIT
+python - "$1" "$2" <<'PY' || exit 1
 import sys
 p='/root/repo/vulkan-renderer_amd/csrc/sr_kernels.hip'; s=open(p).read()
 old,new=sys.argv[1],sys.argv[2]
-assert old in s, "pattern not found"
-s=s.replace(old,new)
-open(p,'w').write(s)
+assert s.count(old) == 1, f"pattern found {s.count(old)} times"
+open(p,'w').write(s.replace(old,new))
 PY
-python -c "import __graft_entry__ as g; g.build()" 2>&1 | grep -E "error" ; (timeout 1500 /usr/local/graft/bin/gpurun --timeout 600 -- "timeout -k 10 300 python -u bench.py --steps 20 --no-cpu-baseline > gpurun_out/bench_a.log 2>&1; echo exit=\$?; tail -2 gpurun_out/bench_a.log") 2>&1 | grep "^{" | python -c "
+python -c "import __graft_entry__ as g; g.build()" || exit 1
+SR_TEST_EMULATED=1 timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > /tmp/emu_gate.log 2>&1 \
+    || { echo "the edit fails on the CPU execution harness: not going to the GPU"; tail -30 /tmp/emu_gate.log; exit 1; }
+(timeout 1500 /usr/local/graft/bin/gpurun --timeout 600 -- "timeout -k 10 300 python -u bench.py --steps 20 --no-cpu-baseline > gpurun_out/bench_a.log 2>&1 || { tail -5 gpurun_out/bench_a.log; exit 1; }; tail -1 gpurun_out/bench_a.log") 2>&1 | grep "^{" | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_ms'])"
-cp /tmp/sr_kernels.exp.bak vulkan-renderer_amd/csrc/sr_kernels.hip; python -c "import __graft_entry__ as g; g.build()"
