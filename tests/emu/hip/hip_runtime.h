@@ -6,8 +6,8 @@
 // Nothing under tests/emu is part of the shipped library: the library is built by hipcc for gfx950
 // from the same sources and has no CPU path.
 //
-// Semantics kept: grid/block indexing, wave64 lanes, __syncthreads, __ballot/__shfl* among the lanes
-// that reach the call, sequentially consistent atomics, uninitialised device memory (filled with a
+// Semantics kept: grid/block indexing, wave64 lanes, __syncthreads, __ballot/__shfl* in wave-uniform
+// control flow (reported as an error otherwise), sequentially consistent atomics, uninitialised device memory (filled with a
 // pattern), no-access pages on both sides of every device allocation.
 // Semantics NOT kept: concurrency between workgroups and between waves (lanes run one after another
 // between synchronisation points, order selectable for race hunting), timing, hardware rounding of

@@ -2,9 +2,9 @@
 // One OS thread; every work-item of the workgroup being executed is a fibre (own stack, hand-written
 // x86-64 register switch: swapcontext costs two system calls per switch).  A fibre runs
 // until it reaches __syncthreads, a wave-wide exchange (__ballot/__shfl*) or the end of the kernel;
-// when every live fibre is parked the scheduler releases, wave by wave, the group of lanes parked at
-// the lowest call site (inner branches and loop bodies come before their join point), and when only
-// barrier waiters are left it releases the barrier.  Device and pinned allocations sit between
+// when every live fibre is parked the scheduler releases the waves whose lanes all wait at one call
+// site (a wave-wide operation that only part of a wave's live lanes reaches is reported as an error
+// rather than emulated), and when only barrier waiters are left it releases the barrier.  Device and pinned allocations sit between
 // no-access pages, so an out-of-range load or store of a kernel raises SIGSEGV here instead of taking
 // a GPU down; the handler turns it into a sticky hipErrorIllegalAddress that names the kernel, the
 // workgroup, the work-item and the allocation next to the address.
@@ -236,6 +236,17 @@ bool run_block(uint32_t n)
             if (!site) continue;
             WaveResult& r = g_wave_result[w];
             r.pred_mask = r.group_mask = 0;
+            // Every live lane of the wave must be at this call: which lanes a wave-wide operation inside divergent
+            // control flow sees depends on how the hardware reconverges, which cannot be reproduced from call
+            // addresses alone.  The kernels keep their wave-wide operations in uniform control flow; anything
+            // else is reported instead of being emulated approximately.
+            for (uint32_t t = lo; t < hi; ++t)
+                if (fb[t].state != DONE && (fb[t].state != AT_WAVE || fb[t].site != site)) {
+                    g_running = &fb[t];
+                    note_error("a wave-wide operation (__ballot/__shfl*) is not reached by every live lane of its wave");
+                    g_running = nullptr;
+                    return false;
+                }
             for (uint32_t t = lo; t < hi; ++t) {
                 Fiber& f = fb[t];
                 r.value[t - lo] = 0;

@@ -5,6 +5,8 @@
 
 #include <cstdio>
 
+extern "C" void hipemu_reset_error(void);
+
 __global__ void copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst)
 {
     __shared__ uint32_t stage[64];
@@ -12,6 +14,15 @@ __global__ void copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restri
     __syncthreads();
     const uint64_t m = __ballot(stage[threadIdx.x & 63u] & 1u);
     dst[threadIdx.x] = stage[(threadIdx.x + 1u) & 63u] + (uint32_t)__popcll(m) + (uint32_t)__shfl((int)threadIdx.x, 3);
+}
+
+// a wave-wide operation inside divergent control flow is refused, not guessed at
+__global__ void divergent_kernel(uint64_t* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t inner = 0;
+    if (lane < 20u) inner = __ballot(lane & 1u);
+    out[threadIdx.x] = inner + __ballot(lane >= 60u);
 }
 
 int main()
@@ -31,5 +42,11 @@ int main()
     std::printf("%s\n", hipGetErrorString(e));
     void* more = nullptr;
     if (hipMalloc(&more, 16) == hipSuccess) { std::printf("the error is not sticky\n"); return 6; }
+    hipemu_reset_error();
+    uint64_t* d = nullptr;
+    if (hipMalloc((void**)&d, 128 * 8) != hipSuccess) return 2;
+    ::hipemu::Launch(dim3(1), dim3(128)).go("divergent_kernel", divergent_kernel, d);
+    if (hipGetLastError() != hipErrorLaunchFailure) { std::printf("a divergent wave-wide operation was not refused\n"); return 7; }
+    std::printf("%s\n", hipGetErrorString(hipErrorLaunchFailure));
     return 0;
 }

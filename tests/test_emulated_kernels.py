@@ -181,3 +181,4 @@ def test_out_of_range_access_is_reported(tmp_path):
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert r.returncode == 0, r.stdout
     assert "memory access fault" in r.stdout and "kernel copy_kernel" in r.stdout and "past its end" in r.stdout, r.stdout
+    assert "not reached by every live lane" in r.stdout and "kernel divergent_kernel" in r.stdout, r.stdout
