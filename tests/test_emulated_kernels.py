@@ -156,7 +156,7 @@ def test_differential_fuzzing_against_the_oracle():
     near-eye-plane vertices is only reported)."""
     build_emulation_library()
     script = os.path.join(ROOT, "tests", "emu", "fuzz_parity.py")
-    runs = [(v, subprocess.Popen([sys.executable, script, str(first), "60"], env=dict(os.environ, SR_VARIANT=v), stdout=subprocess.PIPE,
+    runs = [(v, subprocess.Popen([sys.executable, script, str(first), "24"], env=dict(os.environ, SR_VARIANT=v), stdout=subprocess.PIPE,
                                  stderr=subprocess.STDOUT, text=True))
             for v, first in (("", 0), ("exact_shading", 100), ("cluster_cull_verify,sparse_tail_force,dirty_blocks,exact_shading", 2300), ("anisotropic", 300))]
     for v, proc in runs:
