@@ -79,6 +79,14 @@ def main():
         size = [int(rng.choice([1, 2, 3, 8, 17, 64])) for _ in range(2)]
         images = [sr.scene.noise_rgba(size[0], size[1], seed), sr.scene.constant_rgba(1, 1, (128, 128, 255, 255)),
                   sr.scene.noise_rgba(size[1], size[0], seed + 1), sr.scene.noise_rgba(size[0], size[0], seed + 2)]
+        if seed % 4 == 0:   # the vertex stage on its own: clip coordinates and window-space records, bit for bit
+            mesh = sr.create_mesh_from_data(dev, verts, idx)
+            clip, screen = mesh.vertex_stage(ubos[0], W, H)
+            rclip, rscreen = oracle.vertex_stage(ubos[0], verts, W, H)
+            mesh.destroy()
+            assert np.array_equal(clip.view(np.uint32), rclip.view(np.uint32)), f"seed {seed}: clip coordinates differ"
+            for field in ("X", "Y", "z", "rw"):
+                assert np.array_equal(screen[field].view(np.uint32), rscreen[field].view(np.uint32)), f"seed {seed}: window-space {field} differs"
         got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples, rect=rect)
         for v in range(n_views):
             ref = oracle.draw(ubos[v], verts, idx, images, W, H, samples, rect=rect)
