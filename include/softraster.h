@@ -114,11 +114,14 @@ SR_API int sr_texture_size(sr_texture tex, int* width, int* height);
 SR_API int sr_texture_read_level(sr_device dev, sr_texture tex, int level, void* host_rgba8, size_t bytes);
 
 /* ---- files.  The reference reads its assets through stb_image and Assimp; neither exists here, so the
- * library reads the formats the reference's data directory uses: PNG and glTF 2.0 (.gltf / .glb).
+ * library reads the formats the reference's data directory uses: PNG, JPEG and glTF 2.0 (.gltf / .glb).
  *
  * sr_texture_create_from_file replaces create_texture_from_file, src/texture.hpp:20 / src/texture.cpp:273-291:
  * the file is expanded to 8-bit RGBA as stbi_load(path, ..., STBI_rgb_alpha) does (gray -> R=G=B, no alpha
- * -> 255, 16-bit -> high byte), then handed to sr_texture_create_rgba8_srgb.  PNG only (no interlace). */
+ * -> 255, 16-bit -> high byte), then handed to sr_texture_create_rgba8_srgb.  PNG (no interlace) and
+ * Huffman-coded 8-bit JPEG (baseline and progressive; gray, YCbCr, RGB).  JPEG decoders differ in the last bit
+ * of the inverse DCT, the chroma filter and the colour conversion: the default follows stb_image's arithmetic,
+ * the environment variable SR_JPEG_DECODER=libjpeg selects libjpeg's. */
 SR_API int sr_texture_create_from_file(sr_device dev, const char* path, const sr_sampler_desc* sampler, sr_texture* out);
 /* the decoding step alone (host only, no device): *rgba8_out is width*height*4 bytes, released with sr_image_free */
 SR_API int sr_image_read_file(const char* path, void** rgba8_out, int* width, int* height);

@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "vulkan-renderer_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "libsoftraster_emu.so")
 SOURCES = ("sr_kernels.hip", "sr_api.hip")
-HEADERS = ("sr_device.h", "sr_launch.h", "sr_setup_body.inc", "sr_assets.h", "sr_assets.cpp")
+HEADERS = ("sr_device.h", "sr_launch.h", "sr_setup_body.inc", "sr_assets.h", "sr_assets.cpp", "sr_jpeg.cpp")
 
 _LAUNCH = re.compile(r"([A-Za-z_]\w*(?:<[^<>;()]*>)?)\s*<<<(.*?)>>>\s*\(")
 
@@ -52,7 +52,7 @@ def build(force: bool = False, opt: str = "-O1") -> str:
         units.append(dst)
     cmd = ["g++", "-std=c++17", opt, "-g", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden",
            "-Wl,-Bsymbolic", "-Wno-unknown-pragmas", "-U_FORTIFY_SOURCE",
-           "-I", HERE, "-I", CSRC, *units, os.path.join(CSRC, "sr_assets.cpp"), os.path.join(HERE, "hipemu.cpp"), "-lz", "-o", LIB]
+           "-I", HERE, "-I", CSRC, *units, os.path.join(CSRC, "sr_assets.cpp"), os.path.join(CSRC, "sr_jpeg.cpp"), os.path.join(HERE, "hipemu.cpp"), "-lz", "-o", LIB]
     subprocess.check_call(cmd)
     return LIB
 
@@ -69,7 +69,7 @@ def build_sanitized(force: bool = False) -> str:
     units = [os.path.join(BUILD, f.replace(".hip", "_emu.cpp")) for f in SOURCES]
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-march=x86-64-v3", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize=alignment",
            "--param", "asan-stack=0", "-static-libasan", "-static-libubsan", "-Wno-unknown-pragmas", "-Wno-subobject-linkage", "-U_FORTIFY_SOURCE",
-           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), *units, os.path.join(CSRC, "sr_assets.cpp"),
+           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), *units, os.path.join(CSRC, "sr_assets.cpp"), os.path.join(CSRC, "sr_jpeg.cpp"),
            os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "asan_scenes.cpp"), "-lz", "-o", exe]
     subprocess.check_call(cmd)
     return exe

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY: byte-level mutations (bit flips, truncations, 32-bit overwrites, number swaps in the JSON, insertions) of valid PNG, .gltf and .glb files, fed to the readers of vulkan-renderer_amd/csrc/sr_assets.cpp built with
+"""TEST INFRASTRUCTURE ONLY: byte-level mutations (bit flips, truncations, 32-bit overwrites, number swaps in the JSON, insertions) of valid PNG, JPEG, .gltf and .glb files, fed to the readers of vulkan-renderer_amd/csrc/sr_assets.cpp and sr_jpeg.cpp built with
 AddressSanitizer and UndefinedBehaviorSanitizer (tests/emu/asan_files.cpp).  The readers may refuse a file; any sanitizer report
 fails the run.    python tests/emu/fuzz_files.py [seed [rounds of 100 files]]"""
 import os, sys, subprocess, json, random, struct
@@ -11,7 +11,7 @@ from pathlib import Path
 out = Path('/tmp/file_fuzz'); out.mkdir(exist_ok=True)
 exe = str(out / 'asan_files')
 subprocess.check_call(['g++','-std=c++17','-O1','-g','-fsanitize=address,undefined','-fno-sanitize-recover=all','-static-libasan','-static-libubsan',
-  '-I',os.path.join(ROOT, 'vulkan-renderer_amd', 'csrc'),os.path.join(ROOT, 'tests', 'emu', 'asan_files.cpp'),os.path.join(ROOT, 'vulkan-renderer_amd', 'csrc', 'sr_assets.cpp'),'-lz','-o',exe])
+  '-I',os.path.join(ROOT, 'vulkan-renderer_amd', 'csrc'),os.path.join(ROOT, 'tests', 'emu', 'asan_files.cpp'),os.path.join(ROOT, 'vulkan-renderer_amd', 'csrc', 'sr_assets.cpp'),os.path.join(ROOT, 'vulkan-renderer_amd', 'csrc', 'sr_jpeg.cpp'),'-lz','-o',exe])
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 seeds = []
 # valid seed files
@@ -22,6 +22,14 @@ for (ct, d) in [(0,1),(0,8),(0,16),(2,8),(3,2),(3,8),(4,8),(6,8),(6,16)]:
     samples = nr.integers(0, 1<<d, size=(h, w*ch))
     p = out / f'seed_{ct}_{d}.png'
     F.write_png(str(p), F._pack_rows(samples, d), w, h, ct, d, filters=[0,1,2,3,4], plte=list(range(48)) if ct==3 else None, trns=[1,2,3] if ct==3 else None)
+    seeds.append(p)
+for n, kw in enumerate([dict(subsampling=2), dict(subsampling=1, progressive=True), dict(subsampling=0, progressive=True, optimize=True), dict(restart_marker_blocks=2)]):
+    p = out / f'seed_{n}.jpg'
+    F._test_picture(37, 21, n, gray=(n == 3)).save(str(p), 'JPEG', quality=85, **kw)
+    seeds.append(p)
+for n, spec in enumerate([F.JPEG_STRUCTURES[i] for i in (1, 3, 8, 9, 10)]):
+    p = out / f'seed_s{n}.jpg'
+    F.write_baseline_jpeg(str(p), 29, 19, seed=n, **spec)
     seeds.append(p)
 meshes = [sr.scene.uv_sphere(5,4), sr.scene.screen_quad()]
 for embed, name in (('data','a.gltf'),('glb','b.glb')):

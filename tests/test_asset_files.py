@@ -1,5 +1,7 @@
 """File readers behind create_texture_from_file and Model::load (host-only entry points of the C ABI;
-no GPU needed).  PNG: files written here in every colour type / bit depth / filter, decoded by the
+no GPU needed).  JPEG: files written by libjpeg-turbo (Pillow) and by a small encoder here, decoded by the
+library's libjpeg flavour (bit for bit what libjpeg-turbo gives) and its default stb_image flavour; and
+the JPEG the reference ships.  PNG: files written here in every colour type / bit depth / filter, decoded by the
 library and by Pillow (what stb_image's STBI_rgb_alpha expansion amounts to); and the two PNGs the
 reference ships, read where they lie.  glTF: files written here (data: uri, external .bin, .glb; triangle
 list, strip and fan; strided and normalised accessors) and read back as the arrays that went in."""
@@ -145,6 +147,268 @@ def test_reference_textures_decode_like_pillow(sr, name, lo, hi):
     assert got.shape == (2048, 2048, 4) and np.array_equal(got, exp)
     assert int(got[..., 0].min()) == lo and int(got[..., 0].max()) == hi and (got[..., 3] == 255).all()
     assert np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
+
+
+# ---------------------------------------------------------------------------------------------- JPEG
+ZIGZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
+          57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _libjpeg(path):
+    """What libjpeg-turbo (through Pillow) makes of the file, as RGBA."""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGBA"))
+
+
+def _test_picture(w, h, seed, gray=False):
+    from PIL import Image
+    y, x = np.mgrid[0:h, 0:w]
+    a = np.stack([(x * 7 + y * 3) & 255, ((x ^ y) * 5) & 255, (x * y) & 255], -1)
+    a = (a // 2 + np.random.default_rng(seed).integers(0, 128, a.shape)).astype(np.uint8)   # structure plus noise: every coefficient is busy
+    im = Image.fromarray(a, "RGB")
+    return im.convert("L") if gray else im
+
+
+JPEG_SIZES = [(64, 48), (17, 13), (1, 1), (2, 2), (3, 5), (5, 3), (33, 31), (100, 75), (16, 16), (15, 17)]
+
+
+@pytest.mark.parametrize("progressive", [False, True])
+@pytest.mark.parametrize("layout", ["gray", "444", "422", "420"])
+def test_jpeg_matches_libjpeg(sr, tmp_path, monkeypatch, layout, progressive):
+    """Files written by libjpeg-turbo (Pillow): baseline and progressive (spectral selection and successive
+    approximation, end-of-band runs), 4:4:4 / 4:2:2 / 4:2:0 and gray, three qualities, restart markers, optimised
+    Huffman tables, sizes that are not whole MCUs.  The libjpeg flavour of the reader must give the same bytes as
+    libjpeg-turbo; the default flavour (stb_image's arithmetic) must stay within a few code values of it."""
+    for n, (w, h) in enumerate(JPEG_SIZES):
+        for quality in (30, 90, 100):
+            for extra in ({}, {"restart_marker_blocks": 3}, {"optimize": True}):
+                path = str(tmp_path / "t.jpg")
+                kw = dict(quality=quality, progressive=progressive, **extra)
+                if layout != "gray":
+                    kw["subsampling"] = {"444": 0, "422": 1, "420": 2}[layout]
+                _test_picture(w, h, n, gray=layout == "gray").save(path, "JPEG", **kw)
+                exp = _libjpeg(path)
+                monkeypatch.setenv("SR_JPEG_DECODER", "libjpeg")
+                got = sr.read_image(path)
+                assert got.shape == exp.shape and np.array_equal(got, exp), (w, h, quality, extra)
+                monkeypatch.delenv("SR_JPEG_DECODER")
+                stb = sr.read_image(path)
+                d = np.abs(stb.astype(int) - exp.astype(int)).max(axis=-1)
+                dw = (w + 1) // 2
+                if layout == "422":
+                    d[:, 2 * dw - 2] = 0    # stb_image weighs the last interpolated column the other way round
+                if layout in ("gray", "444") or dw > 2:   # (libjpeg repeats samples instead of filtering when a chroma row has one or two)
+                    assert d.max() <= 3, (w, h, quality, extra, int(d.max()))
+
+
+def _huffman_table(symbols, skewed):
+    """A valid code for the symbols: all eight bits long, or short codes for the first few and 16-bit codes
+    for the rest (the decoder's slow path).  Returns (counts[16], symbols in code order, {symbol: (code, length)})."""
+    if not skewed or len(symbols) < 8:
+        n_bits = 4 if len(symbols) < 15 else 8
+        lengths = [n_bits] * len(symbols)
+    else:
+        lengths = ([3] + [4] * 2 + [5] * 4 + [6] * 8 + [7] * 16 + [8] * 32)[:len(symbols)]
+        lengths += [16] * (len(symbols) - len(lengths))
+    counts, codes, code, k = [0] * 16, {}, 0, 0
+    for length in range(1, 17):
+        for _ in range(lengths.count(length)):
+            codes[symbols[k]] = (code, length)
+            code += 1
+            k += 1
+        counts[length - 1] = lengths.count(length)
+        code <<= 1
+    return counts, symbols, codes
+
+
+class _Bits:
+    def __init__(self):
+        self.out, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, value, length):
+        self.acc = (self.acc << length) | (value & ((1 << length) - 1))
+        self.n += length
+        while self.n >= 8:
+            b = (self.acc >> (self.n - 8)) & 255
+            self.out.append(b)
+            if b == 0xFF:
+                self.out.append(0)
+            self.n -= 8
+
+    def flush(self):
+        if self.n & 7:
+            self.put((1 << (8 - (self.n & 7))) - 1, 8 - (self.n & 7))
+
+
+def write_baseline_jpeg(path, width, height, comps, seed, scans=None, restart=0, skewed=False, wide_quant=False, jfif=True,
+                        adobe_transform=None, fill_bytes=False):
+    """A baseline JPEG made of random quantised coefficients (no picture behind it: the decoders are compared on
+    whatever it decodes to).  comps: [(id, h, v)]; scans: lists of component indices, default one interleaved scan."""
+    rng = np.random.default_rng(seed)
+    hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
+    mcux, mcuy = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    seg = lambda m, body: bytes([0xFF, m]) + struct.pack(">H", len(body) + 2) + body
+    out = bytearray(b"\xff\xd8")
+    if jfif:
+        out += seg(0xE0, b"JFIF\0\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    if adobe_transform is not None:
+        out += seg(0xEE, b"Adobe\0\x64\0\0\0\0" + bytes([adobe_transform]))
+    quant = rng.integers(1, 12, size=(2, 64))
+    for t in range(2):
+        out += seg(0xDB, bytes([0x10 | t]) + b"".join(struct.pack(">H", int(q)) for q in quant[t]) if wide_quant else bytes([t]) + bytes(int(q) for q in quant[t]))
+    out += seg(0xC0, struct.pack(">BHHB", 8, height, width, len(comps)) + b"".join(bytes([cid, (h << 4) | v, min(i, 1)]) for i, (cid, h, v) in enumerate(comps)))
+    dc_counts, dc_syms, dc_codes = _huffman_table(list(range(12)), False)
+    ac_syms = [0x00, 0xF0] + [(r << 4) | s for s in range(1, 11) for r in range(16)]
+    ac_counts, ac_syms, ac_codes = _huffman_table(ac_syms, skewed)
+    out += seg(0xC4, bytes([0x00]) + bytes(dc_counts) + bytes(dc_syms) + bytes([0x10]) + bytes(ac_counts) + bytes(ac_syms))
+    if restart:
+        out += seg(0xDD, struct.pack(">H", restart))
+    # coefficients in zig-zag order for every block the frame allocates; sparse, small
+    coefs = []
+    for (cid, h, v) in comps:
+        c = rng.integers(-20, 21, size=(mcuy * v, mcux * h, 64)) * (rng.random((mcuy * v, mcux * h, 64)) < 0.15)
+        c[..., 0] = rng.integers(-40, 41, size=c.shape[:2])
+        c[..., 63] = rng.integers(-2, 3, size=c.shape[:2])     # the last coefficient too, now and then after a long zero run
+        c[::3, ::2, 1:] = 0                                      # and blocks with a DC term only
+        coefs.append(c)
+
+    def magnitude(bits, v):
+        s = int(abs(v)).bit_length()
+        bits.put(v if v >= 0 else v + (1 << s) - 1, s)
+
+    for scan in (scans or [list(range(len(comps)))]):
+        if fill_bytes:
+            out += b"\xff\xff\xff"
+        out += seg(0xDA, bytes([len(scan)]) + b"".join(bytes([comps[i][0], 0x00]) for i in scan) + bytes([0, 63, 0]))
+        bits, pred, count, rst = _Bits(), [0] * len(comps), 0, 0
+        if len(scan) == 1:
+            cid, h, v = comps[scan[0]]
+            nx, ny = -(-(-(-width * h // hmax)) // 8), -(-(-(-height * v // vmax)) // 8)
+        else:
+            nx, ny = mcux, mcuy
+        for my in range(ny):
+            for mx in range(nx):
+                if restart and count == restart:
+                    bits.flush()
+                    bits.out += bytes([0xFF, 0xD0 + rst])
+                    rst, count, pred = (rst + 1) & 7, 0, [0] * len(comps)
+                count += 1
+                for i in scan:
+                    cid, h, v = comps[i]
+                    for by in range(v if len(scan) > 1 else 1):
+                        for bx in range(h if len(scan) > 1 else 1):
+                            blk = coefs[i][my * (v if len(scan) > 1 else 1) + by, mx * (h if len(scan) > 1 else 1) + bx]
+                            diff = int(blk[0]) - pred[i]
+                            pred[i] = int(blk[0])
+                            bits.put(*dc_codes[int(abs(diff)).bit_length()])
+                            magnitude(bits, diff)
+                            run = 0
+                            last = max([k for k in range(1, 64) if blk[k]], default=0)
+                            for k in range(1, last + 1):
+                                if blk[k] == 0:
+                                    run += 1
+                                    continue
+                                while run > 15:
+                                    bits.put(*ac_codes[0xF0])
+                                    run -= 16
+                                bits.put(*ac_codes[(run << 4) | int(abs(blk[k])).bit_length()])
+                                magnitude(bits, int(blk[k]))
+                                run = 0
+                            if last < 63:
+                                bits.put(*ac_codes[0x00])
+        bits.flush()
+        out += bits.out
+    out += b"\xff\xd9"
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
+JPEG_STRUCTURES = [
+    dict(comps=[(1, 1, 1), (2, 1, 1), (3, 1, 1)]),
+    dict(comps=[(1, 1, 2), (2, 1, 1), (3, 1, 1)]),                                # 4:4:0, the filter that runs down only
+    dict(comps=[(1, 4, 1), (2, 1, 1), (3, 1, 1)]),                                # 4:1:1, samples repeated four times
+    dict(comps=[(1, 4, 1), (2, 2, 1), (3, 1, 1)]),                                # a different ratio per component
+    dict(comps=[(1, 2, 2), (2, 2, 1), (3, 1, 2)]),
+    dict(comps=[(1, 3, 1), (2, 1, 1), (3, 1, 1)]),
+    dict(comps=[(1, 1, 3), (2, 1, 1), (3, 1, 1)]),
+    dict(comps=[(1, 2, 2), (2, 1, 1), (3, 1, 1)], scans=[[0], [1], [2]]),         # one scan per component
+    dict(comps=[(1, 2, 1), (2, 1, 1), (3, 1, 1)], scans=[[0], [1, 2]], restart=2),
+    dict(comps=[(1, 2, 2), (2, 1, 1), (3, 1, 1)], restart=1, skewed=True),
+    dict(comps=[(1, 2, 2), (2, 1, 1), (3, 1, 1)], restart=5, wide_quant=True, fill_bytes=True),
+    dict(comps=[(7, 2, 2)]),                                                      # gray whose sampling factors mean nothing
+    dict(comps=[(1, 1, 1)], restart=3, skewed=True),
+    dict(comps=[(82, 1, 1), (71, 1, 1), (66, 1, 1)], jfif=False),                 # components named R, G, B: no colour transform
+    dict(comps=[(1, 2, 1), (2, 1, 1), (3, 1, 1)], jfif=False, adobe_transform=0),
+    dict(comps=[(1, 2, 1), (2, 1, 1), (3, 1, 1)], jfif=False, adobe_transform=1),
+]
+
+
+@pytest.mark.parametrize("case", range(len(JPEG_STRUCTURES)))
+def test_jpeg_structures_libjpeg_turbo_does_not_write(sr, tmp_path, monkeypatch, case):
+    """Sampling ratios, scan layouts, restart intervals, 16-bit quantisation tables, 16-bit Huffman codes, fill
+    bytes and colour-space markers that Pillow's encoder never produces, written by the small encoder above;
+    libjpeg-turbo (through Pillow) still decodes them and is the reference."""
+    spec = JPEG_STRUCTURES[case]
+    for n, (w, h) in enumerate([(40, 24), (37, 29), (7, 9), (65, 33)]):
+        path = str(tmp_path / "s.jpg")
+        write_baseline_jpeg(path, w, h, seed=case * 10 + n, **spec)
+        exp = _libjpeg(path)
+        monkeypatch.setenv("SR_JPEG_DECODER", "libjpeg")
+        got = sr.read_image(path)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (spec, w, h)
+        monkeypatch.delenv("SR_JPEG_DECODER")
+        stb = sr.read_image(path)
+        assert stb.shape == exp.shape and (stb[..., 3] == 255).all()
+        if all(c[1:] == (1, 1) for c in spec["comps"]) or len(spec["comps"]) == 1:   # no upsampling: only the IDCT and the colour arithmetic differ
+            assert np.abs(stb.astype(int) - exp.astype(int)).max() <= 3
+
+
+def test_jpeg_kinds_that_are_refused(sr, tmp_path):
+    from PIL import Image
+    path = str(tmp_path / "cmyk.jpg")
+    Image.new("CMYK", (8, 8), (10, 20, 30, 40)).save(path, "JPEG")
+    with pytest.raises(sr.SoftRasterError, match="three-component"):
+        sr.read_image(path)
+    good = str(tmp_path / "good.jpg")
+    _test_picture(24, 24, 0).save(good, "JPEG")
+    data = open(good, "rb").read()
+    sof = data.index(b"\xff\xc0")
+    for marker, what in ((0xC9, "arithmetic"), (0xC3, "lossless")):
+        bad = tmp_path / "bad.jpg"
+        bad.write_bytes(data[:sof + 1] + bytes([marker]) + data[sof + 2:])
+        with pytest.raises(sr.SoftRasterError, match=what):
+            sr.read_image(str(bad))
+    bad = tmp_path / "deep.jpg"
+    bad.write_bytes(data[:sof + 4] + b"\x0c" + data[sof + 5:])      # 12 bits per sample
+    with pytest.raises(sr.SoftRasterError, match="8-bit"):
+        sr.read_image(str(bad))
+    bad.write_bytes(data[:sof + 5] + b"\x7f\xff\x7f\xff" + data[sof + 9:])   # a size the data cannot hold
+    with pytest.raises(sr.SoftRasterError, match="too short"):
+        sr.read_image(str(bad))
+    cut = tmp_path / "cut.jpg"
+    sos = data.index(b"\xff\xda")
+    cut.write_bytes(data[:sos + (len(data) - sos) * 2 // 3])        # the tail is missing: what is there decodes
+    got = sr.read_image(str(cut))
+    assert got.shape == (24, 24, 4)
+    assert np.array_equal(got[:8], sr.read_image(good)[:8])
+
+
+def test_reference_albedo_texture(sr, monkeypatch):
+    """data/textures/chalet.jpg, the one JPEG the reference ships (4096 x 4096, baseline, 4:2:0), read where it
+    lies: the libjpeg flavour gives libjpeg-turbo's bytes, the default flavour stays within 3 code values of
+    them with more than 95 % of the bytes equal."""
+    path = "/root/reference/data/textures/chalet.jpg"
+    if not os.path.exists(path):
+        pytest.skip("the reference checkout is not present on this machine")
+    exp = _libjpeg(path)
+    monkeypatch.setenv("SR_JPEG_DECODER", "libjpeg")
+    got = sr.read_image(path)
+    assert got.shape == (4096, 4096, 4) and np.array_equal(got, exp)
+    monkeypatch.delenv("SR_JPEG_DECODER")
+    stb = sr.read_image(path)
+    d = np.abs(stb.astype(np.int16) - exp.astype(np.int16))
+    assert d.max() <= 3 and (d == 0).mean() > 0.95 and (stb[..., 3] == 255).all()
+    assert abs(float(stb[..., :3].mean()) - 88.2) < 0.1
 
 
 # ---------------------------------------------------------------------------------------------- glTF

@@ -3,8 +3,8 @@
 //   Model::load              (src/model.cpp:81-98):     Assimp ReadFile(Triangulate | FlipUVs), one StaticMesh per
 //                                                        mesh found by a depth-first walk of the nodes
 // Neither stb nor Assimp exists here, so this file reads the formats the reference's data directory
-// uses itself: PNG (non-interlaced, every colour type and bit depth) and glTF 2.0 (.gltf with data: or
-// file buffers, .glb).  Pure CPU code; nothing here touches the GPU.
+// uses itself: PNG (non-interlaced, every colour type and bit depth), JPEG (sr_jpeg.cpp) and glTF 2.0 (.gltf
+// with data: or file buffers, .glb).  Pure CPU code; nothing here touches the GPU.
 #include "sr_assets.h"
 
 #include <zlib.h>
@@ -153,7 +153,12 @@ bool load_image(const std::string& path, Image& img, std::string& err)
 {
     std::vector<uint8_t> bytes;
     if (!read_file(path, bytes, err)) return false;
-    if (bytes.size() >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) { err = "JPEG decoding is not implemented (PNG only): " + path; return false; }
+    if (bytes.size() >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) {
+        const char* which = std::getenv("SR_JPEG_DECODER");
+        const JpegFlavor flavor = which && !std::strcmp(which, "libjpeg") ? JpegFlavor::LibJpeg : JpegFlavor::Stb;
+        if (!decode_jpeg(bytes.data(), bytes.size(), img, err, flavor)) { err += ": " + path; return false; }
+        return true;
+    }
     if (!decode_png(bytes.data(), bytes.size(), img, err)) { err += ": " + path; return false; }
     return true;
 }

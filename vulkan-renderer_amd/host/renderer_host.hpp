@@ -139,7 +139,7 @@ struct Texture {               // plain struct with manual destroy, as in src/te
     return t;
 }
 
-// src/texture.hpp:20 / src/texture.cpp:273-291 (PNG files; stb's STBI_rgb_alpha expansion)
+// src/texture.hpp:20 / src/texture.cpp:273-291 (PNG and JPEG files; stb's STBI_rgb_alpha expansion)
 [[nodiscard]] inline Texture create_texture_from_file(vkh::GPUDevice& device, const char* texture_path)
 {
     Texture t;

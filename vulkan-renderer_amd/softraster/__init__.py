@@ -235,7 +235,7 @@ def destroy_texture(device: Device, texture: Texture):
 
 def read_image(path: str) -> np.ndarray:
     """Decodes an image file to (h,w,4) uint8 RGBA the way stbi_load(path, ..., STBI_rgb_alpha) expands it
-    (src/texture.cpp:278-279).  Host only.  PNG files."""
+    (src/texture.cpp:278-279).  Host only.  PNG and JPEG files."""
     L = load_library()
     p, w, h = C.c_void_p(), C.c_int(), C.c_int()
     _check(L.sr_image_read_file(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)), "sr_image_read_file")
