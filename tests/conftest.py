@@ -13,6 +13,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+# Within test_gpu_parity.py the tests of the basic draw paths are run before those of the grow-and-repeat,
+# hash-overflow, pass-splitting, target-reuse and file-loading paths: the suite is run with -x, and a failure in
+# one of the special paths should not hide the results of the basic ones.
+RUN_AFTER_THE_BASIC_PARITY_TESTS = ("test_target_is_reused_across_different_draws", "test_cluster_culling_never_drops_a_drawn_triangle",
+                                    "test_model_and_textures_from_files", "test_tile_reference_list_grows_and_the_draw_is_repeated",
+                                    "test_more_distinct_tiles_than_a_binning_block_can_hash", "test_view_batch_split_into_passes")
+
+
+def pytest_collection_modifyitems(config, items):
+    slots = [i for i, it in enumerate(items) if it.fspath.basename == "test_gpu_parity.py"]
+    ordered = sorted((items[i] for i in slots), key=lambda it: it.name.split("[")[0] in RUN_AFTER_THE_BASIC_PARITY_TESTS)   # stable
+    for i, it in zip(slots, ordered):
+        items[i] = it
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as o

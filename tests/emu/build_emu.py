@@ -3,7 +3,9 @@ stand-in HIP header of this directory -> tests/emu/_build/libsoftraster_emu.so.
 
 The product sources are used as they are; the only rewriting is the triple-chevron launch syntax,
 which a host C++ compiler cannot parse:   kernel<<<grid, block, lds, stream>>>(args)
-becomes                                   ::hipemu::Launch(grid, block, lds, stream).go("kernel", kernel, args)
+becomes                                   ::hipemu::Launch(grid, block, lds, stream).bounds(N).go("kernel", kernel, args)
+with N the kernel's __launch_bounds__ where that is a number, so that a block larger than the kernel was compiled
+for is refused here as the GPU refuses it.
 The rewritten copies live in _build/ (git-ignored) and are regenerated whenever a source changes.
 """
 from __future__ import annotations
@@ -24,8 +26,17 @@ HEADERS = ("sr_device.h", "sr_launch.h", "sr_setup_body.inc", "sr_assets.h", "sr
 _LAUNCH = re.compile(r"([A-Za-z_]\w*(?:<[^<>;()]*>)?)\s*<<<(.*?)>>>\s*\(")
 
 
+_BOUNDS = re.compile(r"__launch_bounds__\((\d+)\)\s+void\s+([A-Za-z_]\w*)")
+
+
 def translate(text: str) -> str:
-    out, n = _LAUNCH.subn(lambda m: f'::hipemu::Launch({m.group(2)}).go("{m.group(1)}", {m.group(1)}, ', text)
+    bounds = {name: n for n, name in _BOUNDS.findall(text)}   # kernels whose bound is a number (not a template parameter)
+
+    def launch(m):
+        kernel = m.group(1)
+        bound = bounds.get(kernel.split("<")[0])
+        return f'::hipemu::Launch({m.group(2)})' + (f".bounds({bound})" if bound else "") + f'.go("{kernel}", {kernel}, '
+    out, n = _LAUNCH.subn(launch, text)
     if "<<<" in out:
         raise RuntimeError("a kernel launch was not recognised by the rewriter")
     return out

@@ -119,13 +119,22 @@ const WaveResult& wave_exchange(uint64_t value, bool pred, const void* site);
 void barrier();
 void run_grid(const char* name, dim3 grid, dim3 block, const std::function<void()>& body);
 void note_error(const char* what);
+void refuse_launch(const char* kernel, unsigned max_block);
 
 struct Launch {
     dim3 grid, block;
+    unsigned max_block = 0;   // the kernel's __launch_bounds__, when the build script could read it from the source
     Launch(dim3 g, dim3 b, size_t /*dynamic_lds*/ = 0, hipStream_t /*stream*/ = nullptr) : grid(g), block(b) {}
+    Launch& bounds(unsigned n) { max_block = n; return *this; }
     template <class... P, class... A>
     void go(const char* name, void (*kernel)(P...), A&&... a) const
     {
+        // what the GPU refuses at launch: more work-items in a block than the kernel was compiled for, or more
+        // than 2^32 work-items along x
+        if ((max_block && block.x * block.y * block.z > max_block) || (uint64_t)grid.x * block.x > 0xFFFFFFFFull) {
+            refuse_launch(name, max_block);
+            return;
+        }
         std::tuple<std::decay_t<P>...> params(std::forward<A>(a)...);
         run_grid(name, grid, block, [&]() { std::apply(kernel, params); });
     }

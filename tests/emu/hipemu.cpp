@@ -314,6 +314,16 @@ void note_error(const char* what)
     }
 }
 
+void refuse_launch(const char* kernel, unsigned max_block)
+{
+    if (g_error == hipSuccess) {
+        g_error = hipErrorLaunchFailure;
+        g_error_text = std::string("emulated launch failure: kernel ") + kernel + " launched with a block larger than its __launch_bounds__(" +
+                       std::to_string(max_block) + ") or with more than 2^32 work-items along x";
+        std::fprintf(stderr, "[hipemu] %s\n", g_error_text.c_str());
+    }
+}
+
 const WaveResult& wave_exchange(uint64_t value, bool pred, const void* site)
 {
     Fiber* f = g_running;

@@ -48,5 +48,10 @@ int main()
     ::hipemu::Launch(dim3(1), dim3(128)).go("divergent_kernel", divergent_kernel, d);
     if (hipGetLastError() != hipErrorLaunchFailure) { std::printf("a divergent wave-wide operation was not refused\n"); return 7; }
     std::printf("%s\n", hipGetErrorString(hipErrorLaunchFailure));
+    // a block larger than the kernel's launch bounds is refused at launch, as the GPU refuses it
+    hipemu_reset_error();
+    ::hipemu::Launch(dim3(1), dim3(128)).bounds(64).go("copy_kernel", copy_kernel, src, dst);
+    if (hipGetLastError() != hipErrorLaunchFailure) { std::printf("a launch beyond the kernel's launch bounds was not refused\n"); return 8; }
+    std::printf("%s\n", hipGetErrorString(hipErrorLaunchFailure));
     return 0;
 }
