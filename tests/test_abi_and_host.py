@@ -87,3 +87,31 @@ def test_orbit_cameras(sr):
     assert len({tuple(np.round(e, 4)) for e in eyes}) == 64
     u = sr.scene.orbit_ubos(4, 1920, 1080, first=8, total=64)
     assert u.shape == (4, 52) and np.allclose(u[0, 48:51], eyes[8], atol=1e-6)
+
+
+def test_orbit_camera_follows_the_key_handler(sr):
+    """key_callback, src/main.cpp:223-267: A / D turn the eye about the up vector, W / S turn eye and up about the
+    axis perpendicular to both, 0.1 rad per press; checked against a double-precision rotation."""
+    import math
+
+    def rodrigues(v, angle, axis):
+        axis = axis / np.linalg.norm(axis)
+        return v * math.cos(angle) + np.cross(axis, v) * math.sin(angle) + axis * np.dot(axis, v) * (1 - math.cos(angle))
+
+    eye, up = np.array([2.0, 2.0, 2.0]), np.array([0.0, 0.0, 1.0])
+    cam = sr.scene.OrbitCamera()
+    for k in "WWADSAAAWXD":
+        cam.key(k)
+        if k in "WS":
+            axis = np.cross(eye, up)
+            angle = 0.1 if k == "W" else -0.1
+            eye, up = rodrigues(eye, angle, axis), rodrigues(up, angle, axis)
+        elif k in "AD":
+            eye = rodrigues(eye, 0.1 if k == "A" else -0.1, up)
+        assert cam.camera_pos.dtype == np.float32 and np.allclose(cam.camera_pos, eye, rtol=0, atol=5e-6) and np.allclose(cam.up, up, rtol=0, atol=5e-6), k
+    assert abs(float(np.linalg.norm(cam.camera_pos)) - math.sqrt(12.0)) < 1e-5
+    # three presses of A: the default eye turned by 0.3 rad about +Z
+    cam = sr.scene.OrbitCamera().keys("AAA")
+    assert np.allclose(cam.camera_pos, [2 * math.cos(0.3) - 2 * math.sin(0.3), 2 * math.sin(0.3) + 2 * math.cos(0.3), 2.0], atol=2e-6)
+    ubo = cam.ubo(800, 600)
+    assert ubo.shape == (52,) and np.allclose(ubo[48:51], cam.camera_pos)

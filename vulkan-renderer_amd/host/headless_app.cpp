@@ -2,7 +2,7 @@
 // (device, textures, mesh, uniform buffer) and the same per-frame work (update_uniform_buffer, draw),
 // with the window, swap chain and presentation replaced by a read-back into a PPM file.
 //
-//   headless_app [width height [x_segments y_segments [out.ppm]]] [--model file.gltf|.glb] [--textures albedo.png normal.png metallic.png roughness.png]
+//   headless_app [width height [x_segments y_segments [out.ppm]]] [--model file.gltf|.glb] [--textures albedo.png normal.png metallic.png roughness.png] [--keys WASD...]
 // Without --model the reference's generated UV sphere is drawn (src/main.cpp:94-115), without --textures
 // procedural maps; with them the files go through Model::load (src/main.cpp:289) and
 // create_texture_from_file (src/main.cpp:283-288) and every mesh of the model is drawn.
@@ -73,10 +73,15 @@ int main(int argc, char** argv)
 
     const char* model_path = nullptr;
     const char* texture_paths[4] = {nullptr, nullptr, nullptr, nullptr};
+    const char* keys = "";
     for (int a = 1; a < argc; ++a) {
         if (!std::strcmp(argv[a], "--model") && a + 1 < argc) model_path = argv[a + 1];
         if (!std::strcmp(argv[a], "--textures") && a + 4 < argc) for (int k = 0; k < 4; ++k) texture_paths[k] = argv[a + 1 + k];
+        if (!std::strcmp(argv[a], "--keys") && a + 1 < argc) keys = argv[a + 1];
     }
+    OrbitCamera camera;                                      // src/main.cpp:210-211
+    for (const char* k = keys; *k; ++k) camera.key(*k);      // what key_callback does on each press
+    if (*keys) std::printf("camera %.9g %.9g %.9g up %.9g %.9g %.9g\n", camera.camera_pos.x, camera.camera_pos.y, camera.camera_pos.z, camera.up.x, camera.up.y, camera.up.z);
 
     vkh::GPUDevice device;                                   // Application(): device_{window_}
     // init_vulkan(): four textures, then the model
@@ -89,9 +94,7 @@ int main(int argc, char** argv)
         // The reference loads the model (src/main.cpp:289) but records the draw of its generated sphere; drawing the
         // model's meshes is what a user of Model::load wants to see.  One frame per mesh, last one kept.
         Model model = Model::load(device, model_path);
-        const vec3 eye{2.0f, 2.0f, 2.0f};
-        const UniformBufferObject view = {identity(), look_at(eye, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}),
-                                          perspective(radians(45.0f), static_cast<float>(width) / static_cast<float>(height), 0.1f, 10.0f), eye};
+        const UniformBufferObject view = camera.ubo(width, height);
         for (const Model::Mesh& m : model.meshes()) {
             target.draw(m, view, albedo, normal, metallic, roughness);
             const sr_draw_stats st = target.stats();
@@ -104,10 +107,7 @@ int main(int argc, char** argv)
     }
     StaticMesh mesh = generate_uv_sphere(device, xs, ys);
 
-    const vec3 camera_pos{2.0f, 2.0f, 2.0f}, up{0.0f, 0.0f, 1.0f};   // src/main.cpp:210-211
-    const UniformBufferObject ubo = {                                 // update_uniform_buffer, src/main.cpp:988-1004
-        identity(), look_at(camera_pos, {0.0f, 0.0f, 0.0f}, up),
-        perspective(radians(45.0f), static_cast<float>(width) / static_cast<float>(height), 0.1f, 10.0f), camera_pos};
+    const UniformBufferObject ubo = camera.ubo(width, height);        // update_uniform_buffer, src/main.cpp:988-1004
 
     const int frames = 20;
     target.draw(mesh, ubo, albedo, normal, metallic, roughness);      // warm-up: sizes the per-tile lists

@@ -62,6 +62,17 @@ inline mat4 perspective(float fovy, float aspect, float z_near, float z_far)
     return r;
 }
 
+// glm::rotate(vec3, angle, normal) of glm/gtx/rotate_vector.hpp: mat3(glm::rotate(angle, normal)) * v
+inline vec3 rotate(vec3 v, float angle, vec3 normal)
+{
+    const float c = std::cos(angle), s = std::sin(angle);
+    const vec3 a = normalize(normal), t{(1.0f - c) * a.x, (1.0f - c) * a.y, (1.0f - c) * a.z};
+    const float r00 = c + t.x * a.x, r01 = t.x * a.y + s * a.z, r02 = t.x * a.z - s * a.y;   // first column
+    const float r10 = t.y * a.x - s * a.z, r11 = c + t.y * a.y, r12 = t.y * a.z + s * a.x;
+    const float r20 = t.z * a.x + s * a.y, r21 = t.z * a.y - s * a.x, r22 = c + t.z * a.z;
+    return {(r00 * v.x + r10 * v.y) + r20 * v.z, (r01 * v.x + r11 * v.y) + r21 * v.z, (r02 * v.x + r12 * v.y) + r22 * v.z};
+}
+
 struct UniformBufferObject {   // 204 bytes, memcpy'd per frame by the reference (src/main.cpp:1002)
     mat4 model;
     mat4 view;
@@ -69,6 +80,30 @@ struct UniformBufferObject {   // 204 bytes, memcpy'd per frame by the reference
     vec3 camera_pos;
 };
 static_assert(sizeof(UniformBufferObject) == 204, "layout of src/main.cpp:50-55");
+
+// The camera of the reference's Application: eye and up vector (src/main.cpp:210-211), moved by the W/S/A/D keys
+// in steps of 0.1 rad (key_callback, src/main.cpp:223-267), turned into the per-frame block by
+// update_uniform_buffer (src/main.cpp:988-1004).
+struct OrbitCamera {
+    vec3 camera_pos{2.0f, 2.0f, 2.0f};
+    vec3 up{0.0f, 0.0f, 1.0f};
+
+    void key(char k)   // GLFW_PRESS or GLFW_REPEAT of that key; other keys do nothing
+    {
+        const float step = 0.1f;
+        if (k == 'W' || k == 'S') {            // over the top: eye and up turn about the axis perpendicular to both
+            const vec3 axis = normalize(cross(camera_pos, up));
+            const float angle = k == 'W' ? step : -step;
+            camera_pos = rotate(camera_pos, angle, axis);
+            up = rotate(up, angle, axis);
+        } else if (k == 'A' || k == 'D') camera_pos = rotate(camera_pos, k == 'A' ? step : -step, up);
+    }
+    UniformBufferObject ubo(int width, int height) const
+    {
+        return {identity(), look_at(camera_pos, {0.0f, 0.0f, 0.0f}, up),
+                perspective(radians(45.0f), static_cast<float>(width) / static_cast<float>(height), 0.1f, 10.0f), camera_pos};
+    }
+};
 
 struct Vertex {                // 32 bytes: the vertex input layout of src/mesh.hpp:18-54
     vec3 pos;

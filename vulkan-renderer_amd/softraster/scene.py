@@ -73,6 +73,48 @@ def default_camera_ubo(width: int, height: int, eye=(2.0, 2.0, 2.0), up=(0.0, 0.
     return make_ubo(m, v, p, eye)
 
 
+def rotate_vector(v, angle: float, normal) -> np.ndarray:
+    """glm::rotate(vec3, angle, normal) of glm/gtx/rotate_vector.hpp in float32: mat3(glm::rotate(angle, normal)) * v."""
+    f = np.float32
+    v = np.asarray(v, f)
+    a = _normalize(np.asarray(normal, f)).astype(f)
+    c, s = f(math.cos(float(f(angle)))), f(math.sin(float(f(angle))))
+    t = (f(1.0) - c) * a
+    col0 = np.array([c + t[0] * a[0], t[0] * a[1] + s * a[2], t[0] * a[2] - s * a[1]], f)
+    col1 = np.array([t[1] * a[0] - s * a[2], c + t[1] * a[1], t[1] * a[2] + s * a[0]], f)
+    col2 = np.array([t[2] * a[0] + s * a[1], t[2] * a[1] - s * a[0], c + t[2] * a[2]], f)
+    return ((col0 * v[0] + col1 * v[1]) + col2 * v[2]).astype(f)
+
+
+class OrbitCamera:
+    """The camera of the reference's Application: eye (2,2,2) and up +Z (src/main.cpp:210-211), moved by the
+    W/S/A/D keys in steps of 0.1 rad (key_callback, src/main.cpp:223-267)."""
+
+    def __init__(self):
+        self.camera_pos = np.array([2.0, 2.0, 2.0], np.float32)
+        self.up = np.array([0.0, 0.0, 1.0], np.float32)
+
+    def key(self, k: str) -> None:
+        """One press (or repeat) of a key; keys other than W, S, A, D do nothing."""
+        step = 0.1
+        if k in ("W", "S"):    # over the top: eye and up turn about the axis perpendicular to both
+            axis = _normalize(np.cross(self.camera_pos, self.up).astype(np.float32))
+            angle = step if k == "W" else -step
+            self.camera_pos = rotate_vector(self.camera_pos, angle, axis)
+            self.up = rotate_vector(self.up, angle, axis)
+        elif k in ("A", "D"):
+            self.camera_pos = rotate_vector(self.camera_pos, step if k == "A" else -step, self.up)
+
+    def keys(self, sequence: str) -> "OrbitCamera":
+        for k in sequence:
+            self.key(k)
+        return self
+
+    def ubo(self, width: int, height: int) -> np.ndarray:
+        """update_uniform_buffer, src/main.cpp:988-1004"""
+        return default_camera_ubo(width, height, eye=self.camera_pos, up=self.up)
+
+
 def _rot_axis(axis, angle):
     a = _normalize(axis).astype(np.float64)
     c, s = math.cos(angle), math.sin(angle)
