@@ -65,7 +65,8 @@ typedef struct sr_draw_stats {
     uint64_t triangles;           /* T: triangles submitted */
     uint64_t triangles_binned;    /* surviving triangles that were not resolved by the set-up kernel itself */
     uint64_t tile_refs;           /* (triangle, tile) references emitted for them; 0 if they were resolved without tile lists */
-    uint64_t triangles_unprojectable; /* dropped: a vertex at w <= 0 or outside the guard band */
+    uint64_t triangles_unprojectable; /* dropped: a vertex at w <= 0 or outside the guard band (with the near_clip pipeline
+                                         variant: only those the near-plane clipper could not handle) */
     uint64_t shaded_pixels;       /* Pv: pixels with at least one covered sample */
     uint64_t visible_triangles;   /* F: distinct triangles owning at least one sample */
     uint64_t pixels;              /* P: pixels of the stored rectangle */
@@ -74,6 +75,8 @@ typedef struct sr_draw_stats {
                                      cluster_cull pipeline variant is on */
     uint64_t cull_violations;     /* cluster_cull_verify variant: triangles of would-be-skipped clusters that the per-triangle
                                      path draws or counts; anything but 0 is a bug */
+    uint64_t triangles_clipped;   /* near_clip variant: triangles with a vertex behind the eye that were cut at the near plane
+                                     and drawn (the fixed-function clipping of the reference's pipeline); 0 otherwise */
 } sr_draw_stats;
 
 /* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */

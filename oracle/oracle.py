@@ -63,6 +63,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_near_clip(on: bool):
+    """Switches the near-plane clipper on or off for every later draw (off by default: triangles with a vertex that
+    cannot be projected are dropped and counted)."""
+    lib().sro_set_near_clip(1 if on else 0)
+
+
 def set_anisotropic(on: bool):
     """Switches the specification's anisotropic footprint on or off for every later sample (off by default)."""
     lib().sro_set_anisotropic(1 if on else 0)
@@ -144,7 +150,7 @@ def vertex_stage(ubo52: np.ndarray, verts: np.ndarray, width: int, height: int):
 
 SCREEN_DTYPE = np.dtype([("X", "<i4"), ("Y", "<i4"), ("z", "<f4"), ("rw", "<f4")])
 
-STAT_NAMES = ("tris_in", "tris_front", "tris_clip_culled", "samples_tested", "samples_passed", "shaded_px")
+STAT_NAMES = ("tris_in", "tris_front", "tris_clip_culled", "samples_tested", "samples_passed", "shaded_px", "tris_clipped")
 
 
 def draw(ubo52, verts, indices, textures, width, height, samples=1, rect=None, threads=1, shade=True):
@@ -186,4 +192,4 @@ def draw(ubo52, verts, indices, textures, width, height, samples=1, rect=None, t
     rc = lib().sro_draw(C.byref(a))
     if rc != 0:
         raise ValueError(f"sro_draw failed with {rc}")
-    return {"depth": depth, "tri": tri, "bgra": bgra, "stats": dict(zip(STAT_NAMES, (int(v) for v in stats[:6])))}
+    return {"depth": depth, "tri": tri, "bgra": bgra, "stats": dict(zip(STAT_NAMES, (int(v) for v in stats[:7])))}

@@ -37,7 +37,8 @@
  *     top-left fill rule, pixel centre at +0.5, Vulkan standard 4x sample positions.
  *   - depth at a sample = l0*z0 + l1*z1 + l2*z2 with l_i = float(E_i) * (1/float(2A)).
  *   - a triangle with a vertex at w <= 0 or outside a 2^20-pixel guard band is dropped and
- *     counted; fragments with depth outside [0,1] are dropped (clip volume, no depth clamp).
+ *     counted -- or, with sro_set_near_clip(1), clipped against the near plane (see near_clip_polygon);
+ *     fragments with depth outside [0,1] are dropped (clip volume, no depth clamp).
  *   - texture LOD from coarse 2x2-quad differences, isotropic (the sampler's 16x anisotropy
  *     is recorded but the footprint is implementation-defined; not applied here).
  *   - sRGB encode to 8 bits is defined by 255 thresholds (decode of the half-way codes).
@@ -214,6 +215,26 @@ static void project_vertex(const view_xform* vx, const float* p, int W, int H, f
     sv->rw = rw;
 }
 
+/* Window-space record of a clip-space position that the near-plane clipper produced: the same divide, viewport
+ * transform, guard band and snapping as project_vertex. */
+static void project_clip(const float* clip, int W, int H, screen_vertex* sv)
+{
+    sv->X = 0; sv->Y = 0; sv->z = 0.0f; sv->rw = 0.0f;
+    float w = clip[3];
+    if (!(w > 0.0f)) return;
+    float rw = 1.0f / w;
+    float xd = clip[0] * rw, yd = clip[1] * rw, zd = clip[2] * rw;
+    float hw = (float)W * 0.5f, hh = (float)H * 0.5f;
+    float xf = xd * hw + hw;
+    float yf = yd * (-hh) + hh;
+    if (!(fabsf(xf) <= GUARD_PX) || !(fabsf(yf) <= GUARD_PX)) return;
+    if (!(rw > 0.0f) || isinf(rw)) return;
+    sv->X = (int32_t)rintf(xf * (float)SUBPIX);
+    sv->Y = (int32_t)rintf(yf * (float)SUBPIX);
+    sv->z = zd;
+    sv->rw = rw;
+}
+
 /* verts: n x 8 floats (pos3, normal3, uv2).  clip_out: n x 4 floats (may be NULL).
  * screen_out: n x 16 bytes {int32 X, int32 Y, float z, float 1/w} (may be NULL). */
 SRO_API void sro_vertex_stage(const float* ubo52, const float* verts, uint32_t n, int W, int H,
@@ -280,6 +301,45 @@ static void edge_eval(const tri_setup* t, int64_t px, int64_t py, int64_t* Ea, i
 
 static int floor_div256(int32_t v) { return v >> 8; } /* arithmetic shift: floor */
 
+/* Near-plane clipping (option, off by default: a triangle with a vertex that cannot be projected is then dropped
+ * and counted).  The fixed-function clipper of the reference's pipeline keeps the part of a primitive inside
+ * 0 <= z_c <= w_c (src/main.cpp:559-600 leaves depth clipping on).  Here a triangle with one or two vertices that
+ * cannot be projected is cut along every edge that joins a projectable vertex g in front of the near plane
+ * (z_c > 0) and an unprojectable vertex o (which must lie behind it, z_c < 0), at z_c = 0:
+ *     t = z_g / (z_g - z_o),   (x, y, w) = fma(t, o - g, g),   z = 0,
+ * always computed from g towards o, so that the two triangles sharing the edge get the same point.  Edges between
+ * projectable vertices are left as they are (they stay identical to the neighbouring triangle's edge; what lies
+ * beyond the near plane on them is removed per sample by the depth range test).  The resulting polygon of 3 or 4
+ * projectable vertices is drawn as a fan, under the id of the triangle it came from. */
+static int g_near_clip = 0;
+SRO_API void sro_set_near_clip(int on) { g_near_clip = on; }
+
+/* returns the number of polygon vertices (0: nothing to draw), or -1 if the triangle cannot be clipped this way
+ * (an unprojectable vertex in front of the near plane, or a cut point that cannot be projected): dropped and counted */
+static int near_clip_polygon(const float* c0, const float* c1, const float* c2, const screen_vertex* s0, const screen_vertex* s1,
+                             const screen_vertex* s2, int W, int H, screen_vertex* out /* [4] */)
+{
+    const float* c[3] = { c0, c1, c2 };
+    const screen_vertex* sv[3] = { s0, s1, s2 };
+    int n = 0;
+    for (int i = 0; i < 3; ++i) {
+        int j = i == 2 ? 0 : i + 1;
+        int good_i = sv[i]->rw != 0.0f, good_j = sv[j]->rw != 0.0f;
+        if (good_i) out[n++] = *sv[i];
+        if (good_i == good_j) continue;
+        const float* g = good_i ? c[i] : c[j];
+        const float* o = good_i ? c[j] : c[i];
+        if (!(o[2] < 0.0f)) return -1;
+        if (!(g[2] > 0.0f)) continue;
+        float t = g[2] / (g[2] - o[2]);
+        float cut[4] = { fmaf(t, o[0] - g[0], g[0]), fmaf(t, o[1] - g[1], g[1]), 0.0f, fmaf(t, o[3] - g[3], g[3]) };
+        project_clip(cut, W, H, &out[n]);
+        if (out[n].rw == 0.0f) return -1;
+        ++n;
+    }
+    return n < 3 ? 0 : n;
+}
+
 typedef struct {
     int W, H, S;            /* full frame size and samples per pixel */
     int rx, ry, rw, rh;     /* stored rectangle */
@@ -288,36 +348,57 @@ typedef struct {
 } vis_target;
 
 typedef struct {
-    uint64_t tris_in, tris_culled_clip, tris_front, samples_tested, samples_passed;
+    uint64_t tris_in, tris_culled_clip, tris_front, samples_tested, samples_passed, tris_clipped;
 } raster_stats;
 
-static void raster_band(const screen_vertex* sv, const uint32_t* idx, uint32_t n_tris, const vis_target* vt,
-                        int band_y0, int band_y1 /* absolute pixel rows */, raster_stats* st)
+static void raster_triangle(const tri_setup* tp, uint32_t ti, const vis_target* vt, int band_y0, int band_y1, raster_stats* st)
 {
+    const tri_setup t = *tp;
     const int S = vt->S;
     const int (*samp)[2] = S == 4 ? g_samp4 : g_samp1;
+    int x0 = floor_div256(t.minX), x1 = floor_div256(t.maxX);
+    int y0 = floor_div256(t.minY), y1 = floor_div256(t.maxY);
+    if (x0 < vt->rx) x0 = vt->rx; if (x1 > vt->rx + vt->rw - 1) x1 = vt->rx + vt->rw - 1;
+    if (y0 < band_y0) y0 = band_y0; if (y1 > band_y1 - 1) y1 = band_y1 - 1;
+    for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) for (int s = 0; s < S; ++s) {
+        int64_t px = (int64_t)x * SUBPIX + samp[s][0], py = (int64_t)y * SUBPIX + samp[s][1];
+        int64_t Ea, Eb, Ec; edge_eval(&t, px, py, &Ea, &Eb, &Ec);
+        if (st) st->samples_tested++;
+        if (Ea + t.bias_a < 0 || Eb + t.bias_b < 0 || Ec + t.bias_c < 0) continue;
+        float l0 = (float)Ea * t.rA, l2 = (float)Eb * t.rA, l1 = (float)Ec * t.rA;
+        float z = fmaf(l2, t.z2, fmaf(l1, t.z1, l0 * t.z0));
+        z = z + 0.0f;
+        if (!(z >= 0.0f && z <= 1.0f)) continue;
+        size_t o = ((size_t)(y - vt->ry) * vt->rw + (x - vt->rx)) * S + s;
+        if (z < vt->depth[o]) { vt->depth[o] = z; vt->tri[o] = ti; if (st) st->samples_passed++; }
+    }
+}
+
+static void raster_band(const screen_vertex* sv, const float* clip /* 4 per vertex */, const uint32_t* idx, uint32_t n_tris, const vis_target* vt,
+                        int band_y0, int band_y1 /* absolute pixel rows */, raster_stats* st)
+{
     for (uint32_t ti = 0; ti < n_tris; ++ti) {
         tri_setup t; int needs_clip;
-        const screen_vertex *v0 = &sv[idx[3*(size_t)ti]], *v1 = &sv[idx[3*(size_t)ti+1]], *v2 = &sv[idx[3*(size_t)ti+2]];
+        const uint32_t i0 = idx[3*(size_t)ti], i1 = idx[3*(size_t)ti+1], i2 = idx[3*(size_t)ti+2];
+        const screen_vertex *v0 = &sv[i0], *v1 = &sv[i1], *v2 = &sv[i2];
         if (st) st->tris_in++;
-        if (!setup_triangle(v0, v1, v2, &t, &needs_clip)) { if (st && needs_clip) st->tris_culled_clip++; continue; }
-        if (st) st->tris_front++;
-        int x0 = floor_div256(t.minX), x1 = floor_div256(t.maxX);
-        int y0 = floor_div256(t.minY), y1 = floor_div256(t.maxY);
-        if (x0 < vt->rx) x0 = vt->rx; if (x1 > vt->rx + vt->rw - 1) x1 = vt->rx + vt->rw - 1;
-        if (y0 < band_y0) y0 = band_y0; if (y1 > band_y1 - 1) y1 = band_y1 - 1;
-        for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) for (int s = 0; s < S; ++s) {
-            int64_t px = (int64_t)x * SUBPIX + samp[s][0], py = (int64_t)y * SUBPIX + samp[s][1];
-            int64_t Ea, Eb, Ec; edge_eval(&t, px, py, &Ea, &Eb, &Ec);
-            if (st) st->samples_tested++;
-            if (Ea + t.bias_a < 0 || Eb + t.bias_b < 0 || Ec + t.bias_c < 0) continue;
-            float l0 = (float)Ea * t.rA, l2 = (float)Eb * t.rA, l1 = (float)Ec * t.rA;
-            float z = fmaf(l2, t.z2, fmaf(l1, t.z1, l0 * t.z0));
-            z = z + 0.0f;
-            if (!(z >= 0.0f && z <= 1.0f)) continue;
-            size_t o = ((size_t)(y - vt->ry) * vt->rw + (x - vt->rx)) * S + s;
-            if (z < vt->depth[o]) { vt->depth[o] = z; vt->tri[o] = ti; if (st) st->samples_passed++; }
+        if (!setup_triangle(v0, v1, v2, &t, &needs_clip)) {
+            if (!needs_clip) continue;
+            if (!g_near_clip) { if (st) st->tris_culled_clip++; continue; }
+            screen_vertex poly[4];
+            int n = near_clip_polygon(clip + 4*(size_t)i0, clip + 4*(size_t)i1, clip + 4*(size_t)i2, v0, v1, v2, vt->W, vt->H, poly);
+            if (n < 0) { if (st) st->tris_culled_clip++; continue; }
+            if (n >= 3 && st) st->tris_clipped++;
+            for (int k = 2; k < n; ++k) {
+                int nc;
+                if (!setup_triangle(&poly[0], &poly[k - 1], &poly[k], &t, &nc)) continue;
+                if (st && k == 2) st->tris_front++;
+                raster_triangle(&t, ti, vt, band_y0, band_y1, st);
+            }
+            continue;
         }
+        if (st) st->tris_front++;
+        raster_triangle(&t, ti, vt, band_y0, band_y1, st);
     }
 }
 
@@ -575,7 +656,7 @@ SRO_API void sro_fragment_main(const float* wp, const float* N, const float* cam
 /* Deferred shading of the visibility result                                            */
 /* ------------------------------------------------------------------------------------ */
 typedef struct {
-    const float* verts; const uint32_t* idx; const screen_vertex* sv; const view_xform* vx;
+    const float* verts; const uint32_t* idx; const screen_vertex* sv; const float* clip; const view_xform* vx; int W, H;
     texture tex[4]; /* albedo, normal, metallic, roughness (binding order of src/main.cpp:461-516) */
 } shade_ctx;
 
@@ -588,6 +669,21 @@ static void persp_weights(const tri_setup* t, int64_t px, int64_t py, float* p0,
     float rden = 1.0f / ((q0 + q1) + q2);
     *p0 = q0 * rden; *p1 = q1 * rden; *p2 = q2 * rden;
 }
+/* The same weights for a triangle that reached the frame through the near-plane clipper: one of its vertices has no
+ * window position, so the weights come from the clip-space coordinates (x, y, w) of the original triangle.  With
+ * h_i = (x_i - w_i X, y_i - w_i Y) for the pixel's normalised device coordinates (X, Y), the perspective-correct
+ * weight of vertex i is proportional to cross(h_j, h_k).  Double precision. */
+static void persp_weights_clip(const float* c0, const float* c1, const float* c2, int W, int H, int64_t px, int64_t py,
+                               float* p0, float* p1, float* p2)
+{
+    double hw = 0.5 * W, hh = 0.5 * H;
+    double X = ((double)px / SUBPIX - hw) / hw, Y = (hh - (double)py / SUBPIX) / hh;
+    double h0x = c0[0] - c0[3] * X, h0y = c0[1] - c0[3] * Y, h1x = c1[0] - c1[3] * X, h1y = c1[1] - c1[3] * Y;
+    double h2x = c2[0] - c2[3] * X, h2y = c2[1] - c2[3] * Y;
+    double q0 = h1x * h2y - h1y * h2x, q1 = h2x * h0y - h2y * h0x, q2 = h0x * h1y - h0y * h1x;
+    double rden = 1.0 / ((q0 + q1) + q2);
+    *p0 = (float)(q0 * rden); *p1 = (float)(q1 * rden); *p2 = (float)(q2 * rden);
+}
 static float interp(float p0, float p1, float p2, float a0, float a1, float a2)
 {
     return fmaf(p2, a2, fmaf(p1, a1, p0 * a0));
@@ -599,9 +695,11 @@ static uint32_t shade_pixel(const shade_ctx* c, uint32_t ti, int x, int y)
     const uint32_t i0 = c->idx[3*(size_t)ti], i1 = c->idx[3*(size_t)ti+1], i2 = c->idx[3*(size_t)ti+2];
     tri_setup t; int nc;
     setup_triangle(&c->sv[i0], &c->sv[i1], &c->sv[i2], &t, &nc);
+    const float *k0 = c->clip + 4*(size_t)i0, *k1 = c->clip + 4*(size_t)i1, *k2 = c->clip + 4*(size_t)i2;
     const float *a0 = c->verts + 8*(size_t)i0, *a1 = c->verts + 8*(size_t)i1, *a2 = c->verts + 8*(size_t)i2;
     float p0, p1, p2;
-    persp_weights(&t, (int64_t)x * SUBPIX + HALF, (int64_t)y * SUBPIX + HALF, &p0, &p1, &p2);
+    if (nc) persp_weights_clip(k0, k1, k2, c->W, c->H, (int64_t)x * SUBPIX + HALF, (int64_t)y * SUBPIX + HALF, &p0, &p1, &p2);
+    else persp_weights(&t, (int64_t)x * SUBPIX + HALF, (int64_t)y * SUBPIX + HALF, &p0, &p1, &p2);
     float w0[3], w1[3], w2[3], n0[3], n1[3], n2[3];
     world_pos(c->vx, a0, w0); world_pos(c->vx, a1, w1); world_pos(c->vx, a2, w2);
     mat3_mul_vec3(c->vx->model, a0 + 3, n0); mat3_mul_vec3(c->vx->model, a1 + 3, n1); mat3_mul_vec3(c->vx->model, a2 + 3, n2);
@@ -614,7 +712,8 @@ static uint32_t shade_pixel(const shade_ctx* c, uint32_t ti, int x, int y)
     const int off[3][2] = { {0, 0}, {1, 0}, {0, 1} };
     for (int k = 0; k < 3; ++k) {
         float r0, r1, r2;
-        persp_weights(&t, (int64_t)(qx + off[k][0]) * SUBPIX + HALF, (int64_t)(qy + off[k][1]) * SUBPIX + HALF, &r0, &r1, &r2);
+        if (nc) persp_weights_clip(k0, k1, k2, c->W, c->H, (int64_t)(qx + off[k][0]) * SUBPIX + HALF, (int64_t)(qy + off[k][1]) * SUBPIX + HALF, &r0, &r1, &r2);
+        else persp_weights(&t, (int64_t)(qx + off[k][0]) * SUBPIX + HALF, (int64_t)(qy + off[k][1]) * SUBPIX + HALF, &r0, &r1, &r2);
         uq[k] = interp(r0, r1, r2, a0[6], a1[6], a2[6]);
         vq[k] = interp(r0, r1, r2, a0[7], a1[7], a2[7]);
     }
@@ -681,18 +780,18 @@ typedef struct {
     float* depth_out;            /* rh*rw*S */
     uint32_t* tri_out;           /* rh*rw*S */
     uint8_t* bgra_out;           /* rh*rw*4 */
-    uint64_t* stats_out;         /* 8 values: tris_in, tris_front, tris_clip_culled, samples_tested, samples_passed, shaded_px, 0, 0 */
+    uint64_t* stats_out;         /* 8 values: tris_in, tris_front, tris_clip_culled, samples_tested, samples_passed, shaded_px, tris_clipped, 0 */
 } sro_draw_args;
 
 typedef struct {
-    const sro_draw_args* a; const screen_vertex* sv; const vis_target* vt; const shade_ctx* sc;
+    const sro_draw_args* a; const screen_vertex* sv; const float* clip; const vis_target* vt; const shade_ctx* sc;
     int y0, y1; raster_stats rs; uint64_t shaded; int phase;
 } band_job;
 
 static void* band_main(void* p)
 {
     band_job* j = (band_job*)p;
-    if (j->phase == 0) raster_band(j->sv, j->a->indices, j->a->n_indices / 3, j->vt, j->y0, j->y1, &j->rs);
+    if (j->phase == 0) raster_band(j->sv, j->clip, j->a->indices, j->a->n_indices / 3, j->vt, j->y0, j->y1, &j->rs);
     else if (j->a->bgra_out) shade_band(j->sc, j->vt, j->a->bgra_out, j->y0, j->y1, &j->shaded);
     return NULL;
 }
@@ -705,14 +804,15 @@ SRO_API int sro_draw(const sro_draw_args* a)
     for (uint32_t i = 0; i < a->n_indices; ++i) if (a->indices[i] >= a->n_verts) return -2;
     view_xform vx; view_from_ubo(a->ubo52, &vx);
     screen_vertex* sv = (screen_vertex*)malloc(sizeof(screen_vertex) * (size_t)(a->n_verts ? a->n_verts : 1));
-    for (uint32_t i = 0; i < a->n_verts; ++i) { float clip[4]; project_vertex(&vx, a->verts + 8*(size_t)i, a->W, a->H, clip, &sv[i]); }
+    float* clip = (float*)malloc(16 * (size_t)(a->n_verts ? a->n_verts : 1));
+    for (uint32_t i = 0; i < a->n_verts; ++i) project_vertex(&vx, a->verts + 8*(size_t)i, a->W, a->H, clip + 4*(size_t)i, &sv[i]);
     size_t ns = (size_t)a->rw * a->rh * a->S;
     vis_target vt = { a->W, a->H, a->S, a->rx, a->ry, a->rw, a->rh, NULL, NULL };
     vt.depth = a->depth_out ? a->depth_out : (float*)malloc(ns * 4);
     vt.tri = a->tri_out ? a->tri_out : (uint32_t*)malloc(ns * 4);
     for (size_t i = 0; i < ns; ++i) { vt.depth[i] = 1.0f; vt.tri[i] = 0xFFFFFFFFu; } /* clear, src/main.cpp:919-921 */
     shade_ctx sc; memset(&sc, 0, sizeof sc);
-    sc.verts = a->verts; sc.idx = a->indices; sc.sv = sv; sc.vx = &vx;
+    sc.verts = a->verts; sc.idx = a->indices; sc.sv = sv; sc.clip = clip; sc.vx = &vx; sc.W = a->W; sc.H = a->H;
     for (int k = 0; k < 4; ++k) {
         sc.tex[k].chain = a->tex_chain[k]; sc.tex[k].w = a->tex_w[k]; sc.tex[k].h = a->tex_h[k];
         sc.tex[k].levels = a->tex_chain[k] ? sro_mip_levels(a->tex_w[k], a->tex_h[k]) : 0;
@@ -725,7 +825,7 @@ SRO_API int sro_draw(const sro_draw_args* a)
     for (int phase = 0; phase < 2; ++phase) {
         for (int k = 0; k < nt; ++k) {
             band_job* j = &jobs[k];
-            j->a = a; j->sv = sv; j->vt = &vt; j->sc = &sc; j->phase = phase;
+            j->a = a; j->sv = sv; j->clip = clip; j->vt = &vt; j->sc = &sc; j->phase = phase;
             j->y0 = a->ry + (int)((int64_t)a->rh * k / nt); j->y1 = a->ry + (int)((int64_t)a->rh * (k + 1) / nt);
             if (nt == 1) band_main(j); else pthread_create(&th[k], NULL, band_main, j);
         }
@@ -735,9 +835,9 @@ SRO_API int sro_draw(const sro_draw_args* a)
         st[3] += jobs[k].rs.samples_tested; st[4] += jobs[k].rs.samples_passed; st[5] += jobs[k].shaded;
     }
     /* per-triangle counts are identical in every band; take them from band 0 */
-    st[0] = jobs[0].rs.tris_in; st[1] = jobs[0].rs.tris_front; st[2] = jobs[0].rs.tris_culled_clip;
+    st[0] = jobs[0].rs.tris_in; st[1] = jobs[0].rs.tris_front; st[2] = jobs[0].rs.tris_culled_clip; st[6] = jobs[0].rs.tris_clipped;
     if (a->stats_out) memcpy(a->stats_out, st, sizeof st);
-    free(jobs); free(th); free(sv);
+    free(jobs); free(th); free(sv); free(clip);
     if (!a->depth_out) free(vt.depth);
     if (!a->tri_out) free(vt.tri);
     return 0;

@@ -111,6 +111,9 @@ int main()
             for (Scene& s : scenes) {
                 std::vector<float> ubo(52 * f.views);
                 for (uint32_t v = 0; v < f.views; ++v) look_at_ubo(&ubo[52 * v], f.W, f.H, 2.0f + 0.7f * v, 2.0f - 0.9f * v, 1.0f + v);
+                // the last view of a multi-view frame from inside the scene: triangles behind and across the eye plane
+                // (dropped and counted, or clipped with the near_clip variant)
+                if (f.views > 1) look_at_ubo(&ubo[52 * (f.views - 1)], f.W, f.H, 0.3f, 0.2f, 0.1f);
                 CHECK(sr_draw(dev, tgt, s.mesh, ubo.data(), f.views, 208, tex));
                 for (uint32_t v = 0; v < f.views; ++v) {
                     CHECK(sr_target_readback(dev, tgt, SR_READ_COLOR_BGRA8, v, color.data(), color.size()));

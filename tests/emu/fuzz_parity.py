@@ -57,10 +57,13 @@ def main():
     import test_gpu_parity as T
     sr.LIB_PATH = build_emu.build()
     oracle.set_anisotropic("anisotropic" in os.environ.get("SR_VARIANT", ""))
+    near_clip = "near_clip" in os.environ.get("SR_VARIANT", "")
+    oracle.set_near_clip(near_clip)
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     dev = sr.Device(0)
     worst_frac = 1.0
+    total_clipped = total_dropped = 0
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
         verts, idx = random_scene(rng)
@@ -88,11 +91,13 @@ def main():
             for field in ("X", "Y", "z", "rw"):
                 assert np.array_equal(screen[field].view(np.uint32), rscreen[field].view(np.uint32)), f"seed {seed}: window-space {field} differs"
         got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples, rect=rect)
+        ref_dropped = ref_clipped = 0
         for v in range(n_views):
             ref = oracle.draw(ubos[v], verts, idx, images, W, H, samples, rect=rect)
             what = f"seed {seed} view {v}: {idx.size // 3} triangles, {W}x{H}x{samples}, rect {rect}"
             assert np.array_equal(got[v]["tri"], ref["tri"]), what + f": triangle ids differ at {int((got[v]['tri'] != ref['tri']).sum())} samples"
             assert np.array_equal(got[v]["depth"].view(np.uint32), ref["depth"].view(np.uint32)), what + ": depth bits differ"
+            ref_dropped += ref["stats"]["tris_clip_culled"]; ref_clipped += ref["stats"]["tris_clipped"]
             covered = int((ref["tri"] != 0xFFFFFFFF).any(axis=-1).sum())
             frac, worst = util.color_match_fraction(got[v]["bgra"], ref["bgra"], 1)
             if covered >= 2000:
@@ -100,13 +105,18 @@ def main():
                 # The default shading kernel computes one barycentric weight as 1 - (the other two): on a triangle with a
                 # vertex far outside the frame and almost on the eye plane that loses it (seed 136); the "exact_shading"
                 # variant does not have this weakness and is held to the bar on every frame.
-                if "exact_shading" in os.environ.get("SR_VARIANT", "") or "anisotropic" in os.environ.get("SR_VARIANT", ""):
+                if "exact_shading" in os.environ.get("SR_VARIANT", "") or "anisotropic" in os.environ.get("SR_VARIANT", "") or near_clip:
                     assert frac >= 0.999, what + f": colour within 1 LSB on {frac:.5f} (worst {worst})"
                 elif frac < 0.999:
                     print(what + f": colour within 1 LSB on {frac:.5f} (worst {worst}) -- default shading kernel, known limitation")
             st = got[v]["stats"]
-        assert st["triangles_unprojectable"] == sum(ref_unproj(ubos[v], verts, idx, W, H, oracle) for v in range(n_views)), f"seed {seed}: unprojectable count"
-    print(f"ok: seeds {first}..{first + count - 1}, lowest colour fraction on well-covered frames {worst_frac:.5f}")
+        total_clipped += ref_clipped; total_dropped += ref_dropped
+        if near_clip:   # with the clipper on: dropped are only those it gives up on
+            assert st["triangles_unprojectable"] == ref_dropped and st["triangles_clipped"] == ref_clipped, f"seed {seed}: dropped / clipped counts {st} vs {ref_dropped}, {ref_clipped}"
+        else:
+            assert st["triangles_unprojectable"] == sum(ref_unproj(ubos[v], verts, idx, W, H, oracle) for v in range(n_views)), f"seed {seed}: unprojectable count"
+    print(f"ok: seeds {first}..{first + count - 1}, lowest colour fraction on well-covered frames {worst_frac:.5f}" +
+          (f"; near-plane clipper: {total_clipped} triangles clipped, {total_dropped} given up" if near_clip else ""))
 
 
 def ref_unproj(ubo, verts, idx, W, H, oracle):

@@ -48,12 +48,13 @@ def test_gpu_parity_suite_on_emulated_kernels():
     subset = "soup or huge or golden or split or multi_view or errors or trailing or reused"
     runs = [start_gpu_suite_emulated("forward"), start_gpu_suite_emulated("reverse", select=subset), start_gpu_suite_emulated("shuffle", select=subset)]
     tails = [finish(r) for r in runs]
-    # the two tests that need a real GPU process are the only ones allowed to be skipped
-    assert "2 skipped" in tails[0], tails[0]
+    # the two tests that need a real GPU process and the two cases of the near_clip variant's own test are the only
+    # ones allowed to be skipped
+    assert "4 skipped" in tails[0], tails[0]
 
 
 VARIANTS = ["fused_geometry", "dirty_blocks,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
-            "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512", "anisotropic"]
+            "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic"]
 
 
 def test_pipeline_variants_give_the_same_frames():
@@ -62,8 +63,8 @@ def test_pipeline_variants_give_the_same_frames():
     descending order."""
     build_emulation_library()
     runs = [start_gpu_suite_emulated("forward", SR_VARIANT=v) for v in VARIANTS]
-    runs.append(start_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full or huge or cluster",
-                                         SR_VARIANT="cluster_cull,sparse_tail_force,dirty_blocks,exact_shading"))
+    runs.append(start_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full or huge or cluster or near_plane",
+                                         SR_VARIANT="cluster_cull,sparse_tail_force,dirty_blocks,exact_shading,near_clip"))
     for r in runs:
         finish(r)
 
@@ -158,7 +159,7 @@ def test_scene_driver_under_address_and_ub_sanitizers():
     exe = build_emu.build_sanitized()
     env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     runs = [(v, subprocess.Popen([exe], env=dict(env, SR_VARIANT=v), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-            for v in ("", "cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading,raster_512", "anisotropic,sparse_tail_force,cluster_cull")]
+            for v in ("", "cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic,sparse_tail_force,cluster_cull")]
     for v, proc in runs:
         out, _ = proc.communicate(timeout=1200)
         assert proc.returncode == 0 and "ok: 32 draws" in out and "runtime error" not in out and "AddressSanitizer" not in out, f"variant '{v}':\n{out[-3000:]}"
@@ -174,7 +175,8 @@ def test_differential_fuzzing_against_the_oracle():
     script = os.path.join(ROOT, "tests", "emu", "fuzz_parity.py")
     runs = [(v, subprocess.Popen([sys.executable, script, str(first), "24"], env=dict(os.environ, SR_VARIANT=v), stdout=subprocess.PIPE,
                                  stderr=subprocess.STDOUT, text=True))
-            for v, first in (("", 0), ("exact_shading", 100), ("cluster_cull_verify,sparse_tail_force,dirty_blocks,exact_shading", 2300), ("anisotropic", 300))]
+            for v, first in (("", 0), ("exact_shading", 100), ("cluster_cull_verify,sparse_tail_force,dirty_blocks,exact_shading", 2300), ("anisotropic", 300),
+                             ("near_clip,dirty_blocks", 3400))]
     for v, proc in runs:
         out, _ = proc.communicate(timeout=1500)
         assert proc.returncode == 0 and "ok: seeds" in out, f"variant '{v}':\n{out[-3000:]}"

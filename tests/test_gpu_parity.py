@@ -3,6 +3,7 @@
 Bar: clip coordinates, window-space vertex records, coverage, depth and triangle ids are bit-exact;
 colour is within 1 LSB per 8-bit channel on >= 99.9 % of the pixels (the oracle uses libm powf/log2f,
 the kernels use the GPU's exp2/log2 instructions)."""
+import os
 import numpy as np
 import pytest
 
@@ -83,7 +84,10 @@ def test_huge_triangles_cover_many_tiles(sr, oracle, device):
 
 
 def test_near_plane_crossing_is_dropped_and_counted(sr, oracle, device):
-    verts, idx = sr.scene.screen_quad(z=0.0, half=500.0)   # reaches behind the eye
+    clipping = "near_clip" in os.environ.get("SR_VARIANT", "")
+    # reaches behind the eye.  (At +-500 the cut points at the near plane lie outside the guard band and the clipper of
+    # the near_clip variant gives the triangles up as well -- covered by test_near_plane_clipper.)
+    verts, idx = sr.scene.screen_quad(z=0.0, half=50.0 if clipping else 500.0)
     small, sidx = sr.scene.uv_sphere(16, 16)
     v = np.concatenate([verts, small]); i = np.concatenate([idx, sidx + 4]).astype(np.uint32)
     ubo = sr.scene.default_camera_ubo(320, 240)
@@ -91,8 +95,13 @@ def test_near_plane_crossing_is_dropped_and_counted(sr, oracle, device):
     got = util.gpu_render(sr, device, v, i, images, ubo, 320, 240, 1)[0]
     ref = oracle.draw(ubo, v, i, images, 320, 240, 1)
     _check_view(got, ref)
-    assert ref["stats"]["tris_clip_culled"] == 2
-    assert got["stats"]["triangles_unprojectable"] == 2
+    if clipping:   # the pipeline variant that clips them at the near plane instead
+        assert ref["stats"]["tris_clip_culled"] == 0 and ref["stats"]["tris_clipped"] == 2
+        assert got["stats"]["triangles_unprojectable"] == 0 and got["stats"]["triangles_clipped"] == 2
+        assert (got["tri"] < 2).sum() > 10000    # the quad now fills most of the frame
+    else:
+        assert ref["stats"]["tris_clip_culled"] == 2
+        assert got["stats"]["triangles_unprojectable"] == 2 and got["stats"]["triangles_clipped"] == 0
 
 
 def test_empty_mesh_and_offscreen_mesh(sr, oracle, device):
@@ -270,6 +279,69 @@ def test_tile_reference_list_grows_and_the_draw_is_repeated(sr, oracle, samples)
             assert got[0]["stats"]["tile_refs"] > 64 or got[0]["stats"]["tile_refs"] == 0
             for k in range(2):
                 _check_view(got[k], oracle.draw(ubos[k], verts, idx, images, W, H, samples))
+    finally:
+        dev.close()
+
+
+def _inward_sphere(sr, x_segments, y_segments, radius):
+    """The UV sphere seen from inside: scaled, triangles turned round."""
+    verts, idx = sr.scene.uv_sphere(x_segments, y_segments)
+    verts = verts.copy()
+    verts[:, :3] *= radius
+    verts[:, 3:6] *= -1.0
+    return verts, np.ascontiguousarray(idx.reshape(-1, 3)[:, ::-1]).reshape(-1)
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_near_plane_clipper(sr, oracle, samples):
+    """Pipeline variant near_clip (skipped otherwise): triangles with a vertex behind the eye are cut at the near
+    plane and drawn, as the fixed-function clipper of the reference's pipeline does, instead of dropped.  A ground
+    quad that passes under and behind the camera, and a sphere seen from inside with the eye close to its surface
+    (dozens of triangles reach from behind the eye to beyond the near plane, sharing their cut edges): visibility equals the oracle's
+    clipper bit for bit, colour to the usual bar, in a two-view draw; then a clip list of 8 entries, where the
+    triangles that find no room are dropped and counted."""
+    import math
+    if "near_clip" not in os.environ.get("SR_VARIANT", ""):
+        pytest.skip("needs SR_VARIANT=near_clip")
+    W, H = 256, 160
+    images = sr.scene.material_textures(64, seed=4)
+    ground = np.zeros((4, 8), np.float32)
+    ground[:, :3] = [[-50, -50, 0], [50, -50, 0], [50, 50, 0], [-50, 50, 0]]
+    ground[:, 5] = 1.0
+    ground[:, 6:8] = ground[:, :2] * 0.1
+    ball, ball_idx = _inward_sphere(sr, 32, 20, 1.0)     # triangles larger than the near distance: some span it
+    ball[:, 2] += 1.0                                   # resting on the ground, the eye inside it
+    verts = np.concatenate([ground, ball])
+    idx = np.concatenate([np.array([0, 1, 2, 0, 2, 3], np.uint32), ball_idx + 4]).astype(np.uint32)
+
+    def camera(eye, target):
+        return sr.scene.make_ubo(np.eye(4, dtype=np.float32), sr.scene.look_at(eye, target, (0.0, 0.0, 1.0)),
+                                 sr.scene.perspective(math.radians(45.0), W / H, 0.1, 10.0), eye)
+    ubos = np.stack([camera(np.array([0.0, -0.97, 1.0]), (0.9, -0.5, 1.0)),     # 0.03 from the shell, looking along it
+                     camera(np.array([0.2, 0.1, 1.2]), (0.0, 1.0, 0.3)),        # well inside: nothing of the ball is clipped
+                     camera(np.array([0.3, -2.0, 1.0]), (0.0, 3.0, 0.0))])      # outside: the ground passes under the camera
+    dev = sr.Device(0)
+    try:
+        got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples)
+        clipped = 0
+        for k in range(3):
+            ref = oracle.draw(ubos[k], verts, idx, images, W, H, samples, threads=4)
+            _check_view(got[k], ref)
+            assert ref["stats"]["tris_clip_culled"] == 0
+            clipped += ref["stats"]["tris_clipped"]
+        assert clipped > 40 and got[0]["stats"]["triangles_clipped"] == clipped and got[0]["stats"]["triangles_unprojectable"] == 0
+        assert (got[0]["tri"] != sr.NO_TRIANGLE).mean() > 0.9 and (got[2]["tri"] < 2).sum() > W * H // 4
+    finally:
+        dev.close()
+    os.environ["SR_CLIP_CAPACITY"] = "8"
+    try:
+        dev = sr.Device(0)
+    finally:
+        del os.environ["SR_CLIP_CAPACITY"]
+    try:
+        st = util.gpu_render(sr, dev, verts, idx, images, ubos[:1], W, H, samples)[0]["stats"]
+        ref = oracle.draw(ubos[0], verts, idx, images, W, H, samples, shade=False)["stats"]
+        assert st["triangles_clipped"] <= 8 and st["triangles_clipped"] + st["triangles_unprojectable"] >= ref["tris_clipped"] > 8
     finally:
         dev.close()
 

@@ -67,6 +67,8 @@ enum : unsigned {
                                        //                Vulkan specification spells out (implies dirty_blocks, exact_shading, fused_geometry)
     kVariantRaster512 = 1u << 8,       // "raster_512": the 4-sample tile kernel runs 512 work-items per 32x32 tile; at 1024 it is capped at
                                        //               128 registers and spills 500 bytes per work-item
+    kVariantNearClip = 1u << 9,        // "near_clip": triangles with a vertex that cannot be projected are clipped against the near plane
+                                       //              (sr_device.h) instead of dropped (implies fused_geometry, exact_shading)
     kVariantClusterVerify = 1u << 6,   // "cluster_cull_verify": evaluate the cluster test but skip nothing; count what skipped clusters
                                        //                        would have drawn into sr_draw_stats.cull_violations (for tests)
 };
@@ -85,6 +87,7 @@ unsigned parse_variants(const char* text)
         if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "exact_shading") v |= kVariantExactShading;
         if (name == "raster_512") v |= kVariantRaster512;
+        if (name == "near_clip") v |= kVariantNearClip | kVariantFusedGeometry | kVariantExactShading;
         if (name == "anisotropic") v |= kVariantAnisotropic | kVariantExactShading | kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "cluster_cull") v |= kVariantClusterCull | kVariantFusedGeometry;
         if (name == "cluster_cull_verify") v |= kVariantClusterVerify | kVariantClusterCull | kVariantFusedGeometry;
@@ -104,6 +107,8 @@ struct sr_device_t {
     float* d_thresh = nullptr;   // 255 (+1 pad)
     // scratch reused by every draw on this device (in-order on `stream`)
     DeviceBuffer screen, tile_count, tile_offset, survivors, survivor_count, refs, views, counters;
+    DeviceBuffer clip;           // kVariantNearClip: [state: 4 words][entries: capacity x 8 bytes][records: 2 x capacity x 48 bytes]
+    uint32_t clip_capacity = 65536;   // triangles per pass that can be clipped; more are dropped and counted
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
     struct Staging { ViewXform* h = nullptr; void* d = nullptr; size_t cap = 0 /* bytes */; hipEvent_t ev = nullptr; bool in_flight = false; };   // h: pinned + mapped, d: its device address
@@ -158,7 +163,7 @@ struct sr_target_t {
     uint32_t passes = 0;
     uint32_t* h_counters = nullptr; void* hd_counters = nullptr; size_t h_counters_cap = 0;   // pinned + mapped, [passes][8], written by the scan kernel of the last draw
     uint64_t capacity_at_draw = 0;
-    uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0;
+    uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0, clipped = 0;
     bool sparse = false;        // kVariantSparseTail: the draw being issued (and then: the last draw) uses the sparse tail
     uint64_t cull_violations = 0;   // kVariantClusterVerify: of the last draw
 };
@@ -326,6 +331,8 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
     SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * setup_block_records() * sizeof(BinRecord)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
+    const bool near_clip = (dev->variants & kVariantNearClip) && m->d_pos4;
+    if (near_clip) SR_HIP(dev->clip.ensure(16 + (size_t)dev->clip_capacity * (sizeof(uint2) + 2 * sizeof(ClipRecord))));
     const bool culling = (dev->variants & kVariantClusterCull) && m->d_clusters && m->d_pos4 && tg->cull_views.size() == n_views;
     const size_t view_bytes = (size_t)n_views * (sizeof(ViewXform) + (culling ? sizeof(ViewCull) : 0));   // [transforms][cull constants]
     SR_HIP(dev->views.ensure(view_bytes));
@@ -414,10 +421,21 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
             cull.views = (const ViewCull*)((const char*)dev->views.ptr + (size_t)n_views * sizeof(ViewXform)) + v0;
             cull.violations = (dev->variants & kVariantClusterVerify) ? dev->d_cull_violations : nullptr;
         }
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse, cull);
+        ClipList clip{nullptr, nullptr, 0, nullptr, nullptr};
+        if (near_clip && fused) {
+            clip.state = (uint32_t*)dev->clip.ptr;
+            clip.entries = (uint2*)((char*)dev->clip.ptr + 16);
+            clip.records = (ClipRecord*)((char*)dev->clip.ptr + 16 + (size_t)dev->clip_capacity * sizeof(uint2));
+            clip.capacity = dev->clip_capacity;
+            clip.count = b.counters + 7;   // zeroed with the other counters at the start of the pass
+            SR_HIP(hipMemsetAsync(clip.state, 0, 16, st));
+        }
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse, cull, clip);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
+        // (before the scan / sparse-tail kernel, which reports the number of dropped triangles to the host)
+        if (clip.entries) launch_near_clip(st, m->d_idx, m->n_tris, m->d_pos4, d_views, g, clip, b, tg->d_vis, v0, dirty, pass_counters);
         if (sparse) {   // one kernel resolves whatever set-up left pending; its time is reported as the raster stage
             if (ev) { SR_HIP(hipEventRecord(ev[5], st)); SR_HIP(hipEventRecord(ev[6], st)); }
             launch_sparse_tail(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty, pass_counters);
@@ -451,12 +469,14 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(hipStreamSynchronize(dev->stream));
     if (!tg->check_pending) return SR_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0;
+        uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0, clipped = 0;
+        const bool near_clip = (dev->variants & kVariantNearClip) && tg->mesh && tg->mesh->d_pos4;
         for (uint32_t p = 0; p < tg->passes; ++p) {
             const uint32_t* c = tg->h_counters + (size_t)p * kCountersPerPass;
             worst = std::max<uint64_t>(worst, c[0]); total += c[0]; unproj += c[2]; binned += c[3]; micro += c[4];
+            if (near_clip) clipped += c[6];
         }
-        tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned; tg->micro = micro;
+        tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned; tg->micro = micro; tg->clipped = clipped;
         if (worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
         if (attempt == 1) break;
         dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull);
@@ -521,6 +541,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* e = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(e);
     if (const char* e = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 30;
     if (const char* e = std::getenv("SR_REF_CAPACITY")) dev->ref_capacity = (uint64_t)std::max(1, std::atoi(e));   // initial size of the tile reference list (tests: force the grow-and-redraw path)
+    if (const char* e = std::getenv("SR_CLIP_CAPACITY")) dev->clip_capacity = (uint32_t)std::max(1, std::atoi(e));   // tests: a full clip list
     if (const char* e = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 20;   // small budgets: many passes per draw
     dev->variants = parse_variants(std::getenv("SR_VARIANT"));
     if (dev->variants & kVariantClusterVerify) SR_HIP(hipMalloc((void**)&dev->d_cull_violations, 4));
@@ -535,7 +556,7 @@ int sr_device_destroy(sr_device dev)
     (void)hipStreamSynchronize(dev->stream);
     for (hipEvent_t e : dev->events) (void)hipEventDestroy(e);
     dev->screen.release(); dev->tile_count.release(); dev->tile_offset.release(); dev->survivors.release();
-    dev->survivor_count.release(); dev->refs.release(); dev->views.release(); dev->counters.release();
+    dev->survivor_count.release(); dev->refs.release(); dev->views.release(); dev->counters.release(); dev->clip.release();
     for (auto& sg : dev->staging) { if (sg.h) (void)hipHostFree(sg.h); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     (void)hipFree(dev->d_decode); (void)hipFree(dev->d_thresh); (void)hipFree(dev->d_cull_violations);
     (void)hipStreamDestroy(dev->stream);
@@ -928,6 +949,7 @@ int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)
     out->visible_triangles = h[1];
     out->triangles_binned = target->binned;
     out->triangles_direct = target->micro;
+    out->triangles_clipped = target->clipped;
     if ((dev->variants & kVariantClusterCull) && m->d_clusters && target->cull_views.size() == n_views) {
         // re-evaluate the cluster test for the draw's views (its device copy may have been overwritten by a later draw)
         ViewCull* d_cv = nullptr; uint64_t* d_total = nullptr; uint64_t total = 0;

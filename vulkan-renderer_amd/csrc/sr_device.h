@@ -316,4 +316,78 @@ __device__ inline bool cluster_is_invisible(const ClusterRec& cl, const ViewCull
     return K * gmin * cl.rho_min >= need;
 }
 
+// Near-plane clipping (pipeline variant "near_clip").  By default a triangle with one or two vertices that cannot
+// be projected (w <= 0, or outside the guard band) is dropped and counted.  The fixed-function clipper of the
+// reference's pipeline keeps the part of such a triangle inside 0 <= z_c <= w_c (src/main.cpp:559-600 leaves depth
+// clipping on); with the variant on, the fused set-up kernel lists these triangles and two small kernels draw them:
+//   * near_clip_kernel cuts every edge that joins a projectable vertex g in front of the near plane (z_c > 0) and
+//     an unprojectable vertex o (which must lie behind it, z_c < 0) at z_c = 0:
+//         t = z_g / (z_g - z_o),   (x, y, w) = fma(t, o - g, g),   z = 0,
+//     always from g towards o, so that both triangles sharing the edge get the same point.  Edges between
+//     projectable vertices stay as they are -- identical to the neighbouring triangle's edge; what lies beyond the
+//     near plane on them is removed per sample by the depth range test.  The polygon of 3 or 4 projectable vertices
+//     becomes one or two records of window-space vertices;
+//   * clipped_raster_kernel resolves the records into the visibility buffer under the id of the triangle they came
+//     from, with the edge functions, depth expression and 64-bit min of every other path.
+// The shading pass recognises such a triangle by its unprojectable vertex and interpolates from clip-space
+// coordinates (shade_pixel).
+struct ClipRecord {            // 48 bytes: one piece of a clipped triangle
+    int32_t X[3], Y[3];        // window coordinates, 1/256 pixel
+    float z[3];
+    uint32_t tri, view, pad;
+};
+struct ClipList {
+    uint2* entries;            // (view inside the pass, triangle); null: variant off
+    uint32_t* count;           // entries appended by set-up (may exceed capacity: the excess is counted as dropped)
+    uint32_t capacity;
+    ClipRecord* records;       // [2 * capacity]
+    uint32_t* state;           // [0] records written, [1] triangles clipped
+};
+
+// window-space record of a clip-space position produced by the clipper: the divide, viewport transform, guard band
+// and snapping of project_vertex
+__device__ inline ScreenVertex project_clip_coords(const float* clip, int W, int H)
+{
+    ScreenVertex sv;
+    sv.X = 0; sv.Y = 0; sv.z = 0.0f; sv.rw = 0.0f;
+    const float w = clip[3];
+    if (!(w > 0.0f)) return sv;
+    const float rw = 1.0f / w;
+    const float xd = clip[0] * rw, yd = clip[1] * rw, zd = clip[2] * rw;
+    const float hw = (float)W * 0.5f, hh = (float)H * 0.5f;
+    const float xf = xd * hw + hw;
+    const float yf = yd * (-hh) + hh;
+    if (!(fabsf(xf) <= kGuardPx) || !(fabsf(yf) <= kGuardPx)) return sv;
+    if (!(rw > 0.0f) || isinf(rw)) return sv;
+    sv.X = (int32_t)rintf(xf * (float)kSubpix);
+    sv.Y = (int32_t)rintf(yf * (float)kSubpix);
+    sv.z = zd;
+    sv.rw = rw;
+    return sv;
+}
+
+// number of polygon vertices written to out[4] (0: nothing to draw), or -1 when the triangle cannot be clipped this
+// way (an unprojectable vertex in front of the near plane, or a cut point that cannot be projected)
+__device__ inline int near_clip_polygon(const float (*c)[4] /* clip coordinates of the 3 vertices */, const ScreenVertex* sv /* [3] */, int W, int H, ScreenVertex* out)
+{
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = i == 2 ? 0 : i + 1;
+        const bool good_i = sv[i].rw != 0.0f, good_j = sv[j].rw != 0.0f;
+        if (good_i) out[n++] = sv[i];
+        if (good_i == good_j) continue;
+        const float* g = good_i ? c[i] : c[j];
+        const float* o = good_i ? c[j] : c[i];
+        if (!(o[2] < 0.0f)) return -1;
+        if (!(g[2] > 0.0f)) continue;
+        const float t = g[2] / (g[2] - o[2]);
+        const float cut[4] = { fmaf(t, o[0] - g[0], g[0]), fmaf(t, o[1] - g[1], g[1]), 0.0f, fmaf(t, o[3] - g[3], g[3]) };
+        out[n] = project_clip_coords(cut, W, H);
+        if (out[n].rw == 0.0f) return -1;
+        ++n;
+    }
+    return n < 3 ? 0 : n;
+}
+
 }  // namespace sr

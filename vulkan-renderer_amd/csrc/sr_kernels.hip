@@ -222,12 +222,13 @@ __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__
 
 // Set-up with the vertex stage fused in (see sr_setup_body.inc); pos4: packed positions, views: the
 // transforms of the views of this pass, dirty: optional dirty map (flags == null: not tracked), cull: optional
-// cluster culling (clusters == null: off).
+// cluster culling (clusters == null: off), clip: optional list for triangles that need near-plane clipping
+// (entries == null: they are dropped and counted).
 template <int S>
 __global__ __launch_bounds__(256) void geometry_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                        FrameGeom g, BinBuffers b, unsigned long long* __restrict__ vis, uint32_t view0,
                                                        const float4* __restrict__ pos4, const ViewXform* __restrict__ views, DirtyMap dirty,
-                                                       ClusterCull cull)
+                                                       ClusterCull cull, ClipList clip)
 {
 #define SR_SETUP_FUSED 1
 #include "sr_setup_body.inc"
@@ -734,6 +735,85 @@ __global__ __launch_bounds__(256) void sparse_tail_kernel(const uint32_t* __rest
 }
 
 // =================================================================================================
+// near-plane clipping (pipeline variant, see sr_device.h): one work-item per listed triangle cuts it
+// and writes one or two records of window-space vertices ...
+// =================================================================================================
+__global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, const float4* __restrict__ pos4,
+                                                        const ViewXform* __restrict__ views, FrameGeom g, ClipList clip, uint32_t* __restrict__ counters)
+{
+    const uint32_t n = min(*clip.count, clip.capacity);
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
+        const uint2 entry = clip.entries[e];
+        const uint32_t view = entry.x, tri = entry.y;
+        if (tri >= n_tris) continue;   // (the list only ever holds valid ids; cheap insurance against a fault)
+        float c[3][4];
+        ScreenVertex sv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 q = pos4[idx[3 * (size_t)tri + k]];
+            sv[k] = project_vertex(views[view], q.x, q.y, q.z, g.W, g.H, c[k]);
+        }
+        ScreenVertex poly[4];
+        const int np = near_clip_polygon(c, sv, g.W, g.H, poly);
+        if (np < 0) { atomicAdd(&counters[2], 1u); continue; }   // cannot be clipped against the near plane: dropped and counted
+        if (np == 0) continue;
+        atomicAdd(&clip.state[1], 1u);
+        for (int k = 2; k < np; ++k) {    // fan around the first polygon vertex
+            ClipRecord r;
+            r.X[0] = poly[0].X; r.Y[0] = poly[0].Y; r.z[0] = poly[0].z;
+            r.X[1] = poly[k - 1].X; r.Y[1] = poly[k - 1].Y; r.z[1] = poly[k - 1].z;
+            r.X[2] = poly[k].X; r.Y[2] = poly[k].Y; r.z[2] = poly[k].z;
+            r.tri = tri; r.view = view; r.pad = 0u;
+            clip.records[atomicAdd(&clip.state[0], 1u)] = r;   // at most two per entry: the array holds 2 * capacity
+        }
+    }
+}
+
+// ... and the records are resolved into the visibility buffer in HBM, 8x8 pixels per step; the rows of a record's
+// box are dealt out to kClipSlabs waves, so that a piece that fills the frame does not hang on one wave.
+constexpr uint32_t kClipSlabs = 16;
+template <int S>
+__global__ __launch_bounds__(256) void clipped_raster_kernel(ClipList clip, FrameGeom g, unsigned long long* __restrict__ vis, uint32_t view0, DirtyMap dirty,
+                                                             uint32_t* __restrict__ host_counters)
+{
+    const uint32_t n = min(clip.state[0], 2u * clip.capacity);
+    if (blockIdx.x == 0u && threadIdx.x == 0u) host_counters[6] = clip.state[1];   // triangles clipped in this pass, for the host
+    const uint32_t lane = lane_id();
+    const uint32_t waves_total = gridDim.x * 4u, first = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    for (uint32_t item = first; item < n * kClipSlabs; item += waves_total) {   // every lane of the wave holds the same record
+        const ClipRecord& r = clip.records[item / kClipSlabs];
+        const uint32_t slab = item % kClipSlabs;
+        ScreenVertex v0, v1, v2;
+        v0.X = r.X[0]; v0.Y = r.Y[0]; v0.z = r.z[0]; v0.rw = 1.0f;
+        v1.X = r.X[1]; v1.Y = r.Y[1]; v1.z = r.z[1]; v1.rw = 1.0f;
+        v2.X = r.X[2]; v2.Y = r.Y[2]; v2.z = r.z[2]; v2.rw = 1.0f;
+        const uint32_t tri = r.tri, view = r.view;
+        TriSetup ts;
+        if (setup_triangle(v0, v1, v2, ts) != 1) continue;
+        int x0, x1, y0, y1;
+        pixel_span<S>(ts.minX, ts.maxX, x0, x1);
+        pixel_span<S>(ts.minY, ts.maxY, y0, y1);
+        x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+        y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
+        const bool narrow = fits_32bit(ts);
+        for (int by = y0 + 8 * (int)slab; by <= y1; by += 8 * (int)kClipSlabs)
+            for (int bx = x0; bx <= x1; bx += 8) {
+                const int x = bx + lx, y = by + ly;
+                if (x <= x1 && y <= y1) {
+                    unsigned long long* cell = &vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S];
+                    if (narrow) raster_pixel32<S>(ts, tri, x, y, cell);
+                    else raster_pixel<S>(ts, tri, x, y, cell);
+                }
+                // the step's four corner lanes mark the (at most four) blocks of the dirty map under it
+                if (dirty.flags && (lx == 0 || lx == 7) && (ly == 0 || ly == 7))
+                    mark_dirty(dirty, view0 + view, min(x, x1) - g.rx, min(y, y1) - g.ry);
+            }
+    }
+}
+
+// =================================================================================================
 // stage 4: deferred fragment shading (shaders/shader.frag:102-152) from the visibility buffer
 // =================================================================================================
 struct ShadeTables {
@@ -1037,9 +1117,29 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     const float s = (float)kSubpix * rA;
     const float l1x = e2y * s, l1y = -e2x * s, l2x = -e1y * s, l2y = e1x * s;
     // perspective: attribute = sum(q_i a_i) / sum(q_i), q_i = l_i / w_i, all affine in screen space
-    const float q0 = l0 * v0.rw, q1 = l1 * v1.rw, q2 = l2 * v2.rw;
-    const float q0x = -(l1x + l2x) * v0.rw, q1x = l1x * v1.rw, q2x = l2x * v2.rw;
-    const float q0y = -(l1y + l2y) * v0.rw, q1y = l1y * v1.rw, q2y = l2y * v2.rw;
+    float q0 = l0 * v0.rw, q1 = l1 * v1.rw, q2 = l2 * v2.rw;
+    float q0x = -(l1x + l2x) * v0.rw, q1x = l1x * v1.rw, q2x = l2x * v2.rw;
+    float q0y = -(l1y + l2y) * v0.rw, q1y = l1y * v1.rw, q2y = l2y * v2.rw;
+    if constexpr (EXACT) {
+        if (v0.rw == 0.0f || v1.rw == 0.0f || v2.rw == 0.0f) {
+            // A triangle that reached the frame through the near-plane clipper: a vertex has no window position, so
+            // the weights come from the clip-space coordinates (x, y, w).  With h_i = (x_i - w_i X, y_i - w_i Y) for
+            // the pixel's normalised device coordinates (X, Y), q_i is proportional to cross(h_j, h_k), affine in
+            // (X, Y) like the q_i above (any common factor cancels in the divisions by D below).
+            float wpos[4], c0[4], c1[4], c2[4];
+            mat4_mul_vec4(vx.model, a0.x, a0.y, a0.z, 1.0f, wpos); mat4_mul_vec4(vx.pv, wpos[0], wpos[1], wpos[2], 1.0f, c0);
+            mat4_mul_vec4(vx.model, a1.x, a1.y, a1.z, 1.0f, wpos); mat4_mul_vec4(vx.pv, wpos[0], wpos[1], wpos[2], 1.0f, c1);
+            mat4_mul_vec4(vx.model, a2.x, a2.y, a2.z, 1.0f, wpos); mat4_mul_vec4(vx.pv, wpos[0], wpos[1], wpos[2], 1.0f, c2);
+            const float hw = (float)p.g.W * 0.5f, hh = (float)p.g.H * 0.5f, ihw = 1.0f / hw, ihh = 1.0f / hh;
+            const float X = ((float)x + 0.5f - hw) * ihw, Y = (hh - ((float)y + 0.5f)) * ihh;
+            const float h0x = c0[0] - c0[3] * X, h0y = c0[1] - c0[3] * Y, h1x = c1[0] - c1[3] * X, h1y = c1[1] - c1[3] * Y;
+            const float h2x = c2[0] - c2[3] * X, h2y = c2[1] - c2[3] * Y;
+            q0 = h1x * h2y - h1y * h2x; q1 = h2x * h0y - h2y * h0x; q2 = h0x * h1y - h0y * h1x;
+            q0x = -(c1[3] * h2y - h1y * c2[3]) * ihw; q0y = (h1x * c2[3] - c1[3] * h2x) * ihh;   // one pixel to the right: X + 1/hw; down: Y - 1/hh
+            q1x = -(c2[3] * h0y - h2y * c0[3]) * ihw; q1y = (h2x * c0[3] - c2[3] * h0x) * ihh;
+            q2x = -(c0[3] * h1y - h0y * c1[3]) * ihw; q2y = (h0x * c1[3] - c0[3] * h1x) * ihh;
+        }
+    }
     const float D = q0 + q1 + q2, Dx = q0x + q1x + q2x, Dy = q0y + q1y + q2y;
     const float Nu = fmaf(q2, b2.z, fmaf(q1, b1.z, q0 * b0.z)), Nv = fmaf(q2, b2.w, fmaf(q1, b1.w, q0 * b0.w));
     const float Nux = fmaf(q2x, b2.z, fmaf(q1x, b1.z, q0x * b0.z)), Nvx = fmaf(q2x, b2.w, fmaf(q1x, b1.w, q0x * b0.w));
@@ -1269,13 +1369,13 @@ void launch_pack_positions(hipStream_t st, const void* aos, uint32_t n, void* po
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between,
-                  const void* pos4, const ViewXform* views, const DirtyMap& dirty, bool bin, const ClusterCull& cull)
+                  const void* pos4, const ViewXform* views, const DirtyMap& dirty, bool bin, const ClusterCull& cull, const ClipList& clip)
 {
     if (!n_tris || !n_views) return;
     const dim3 grid(b.n_blocks, n_views);
     if (pos4) {
-        if (g.samples == 1) geometry_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty, cull);
-        else geometry_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty, cull);
+        if (g.samples == 1) geometry_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty, cull, clip);
+        else geometry_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty, cull, clip);
     } else if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
     else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
     if (between) (void)hipEventRecord(between, st);
@@ -1292,6 +1392,15 @@ void launch_sparse_tail(hipStream_t st, const uint32_t* idx, uint32_t n_tris, co
     const uint32_t blocks = std::min<uint32_t>((slices + 3u) / 4u, 1024u);
     if (g.samples == 1) sparse_tail_kernel<1><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
     else sparse_tail_kernel<4><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
+}
+
+void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* pos4, const ViewXform* views, const FrameGeom& g,
+                      const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0, const DirtyMap& dirty, uint32_t* host_counters)
+{
+    // the list is short in any ordinary frame: a few blocks cut it, a few hundred waves share the pieces
+    near_clip_kernel<<<64, 256, 0, st>>>(idx, n_tris, (const float4*)pos4, views, g, clip, b.counters);
+    if (g.samples == 1) clipped_raster_kernel<1><<<512, 256, 0, st>>>(clip, g, (unsigned long long*)vis, view0, dirty, host_counters);
+    else clipped_raster_kernel<4><<<512, 256, 0, st>>>(clip, g, (unsigned long long*)vis, view0, dirty, host_counters);
 }
 
 void launch_count_culled_clusters(hipStream_t st, const ClusterCull& cull, const FrameGeom& g, uint32_t n_clusters, uint32_t n_views, uint64_t* total)

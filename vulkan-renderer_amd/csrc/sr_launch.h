@@ -34,7 +34,13 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
                   const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between /* recorded between set-up and binning, may be null */,
                   const void* pos4 = nullptr, const ViewXform* views = nullptr, const DirtyMap& dirty = DirtyMap{nullptr, 0, 0},
                   bool bin = true /* false: set-up only, the caller resolves the pending triangles with launch_sparse_tail */,
-                  const ClusterCull& cull = ClusterCull{nullptr, nullptr, nullptr});
+                  const ClusterCull& cull = ClusterCull{nullptr, nullptr, nullptr},
+                  const ClipList& clip = ClipList{nullptr, nullptr, 0, nullptr, nullptr} /* with pos4: where triangles that need near-plane clipping are listed */);
+// near-plane clipping of the triangles the fused set-up listed (clip.count must be b.counters + 7, zeroed with the pass;
+// clip.state zeroed by the caller): cuts them, resolves the pieces into the visibility buffer, writes the number of
+// triangles clipped to host_counters[6].  Runs after launch_setup and before launch_scan / launch_sparse_tail.
+void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* pos4, const ViewXform* views, const FrameGeom& g,
+                      const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0, const DirtyMap& dirty, uint32_t* host_counters);
 void launch_count_culled_clusters(hipStream_t st, const ClusterCull& cull, const FrameGeom& g, uint32_t n_clusters, uint32_t n_views, uint64_t* total);
 // resolves every pending triangle of the pass straight into the visibility buffer (in place of bin + scan + fill + raster)
 // and writes the pass's counters to host_counters: [2] unprojectable, [3] pending triangles, [4] micro-triangles, [5] 8x8 steps

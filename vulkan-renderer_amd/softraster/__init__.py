@@ -50,7 +50,8 @@ class Rect(C.Structure):
 
 class DrawStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("vertices", "triangles", "triangles_binned", "tile_refs", "triangles_unprojectable",
-                                           "shaded_pixels", "visible_triangles", "pixels", "triangles_direct", "clusters_culled", "cull_violations")]
+                                           "shaded_pixels", "visible_triangles", "pixels", "triangles_direct", "clusters_culled", "cull_violations",
+                                           "triangles_clipped")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
