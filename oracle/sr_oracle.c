@@ -304,40 +304,78 @@ static int floor_div256(int32_t v) { return v >> 8; } /* arithmetic shift: floor
 /* Near-plane clipping (option, off by default: a triangle with a vertex that cannot be projected is then dropped
  * and counted).  The fixed-function clipper of the reference's pipeline keeps the part of a primitive inside
  * 0 <= z_c <= w_c (src/main.cpp:559-600 leaves depth clipping on).  Here a triangle with one or two vertices that
- * cannot be projected is cut along every edge that joins a projectable vertex g in front of the near plane
- * (z_c > 0) and an unprojectable vertex o (which must lie behind it, z_c < 0), at z_c = 0:
- *     t = z_g / (z_g - z_o),   (x, y, w) = fma(t, o - g, g),   z = 0,
- * always computed from g towards o, so that the two triangles sharing the edge get the same point.  Edges between
- * projectable vertices are left as they are (they stay identical to the neighbouring triangle's edge; what lies
- * beyond the near plane on them is removed per sample by the depth range test).  The resulting polygon of 3 or 4
- * projectable vertices is drawn as a fan, under the id of the triangle it came from. */
+ * cannot be projected is clipped in clip space against the near plane (z >= 0) and then against four side planes
+ * |x| <= K_x w, |y| <= K_y w that keep every cut point 2^19 pixels or less from the frame (inside the guard band):
+ *   - a projectable vertex of the triangle counts as inside every plane, whatever its coordinates: edges between two
+ *     such vertices are never cut and stay identical to the neighbouring triangles' edges (what lies beyond the near
+ *     plane on them is removed per sample by the depth range test);
+ *   - a cut point is always computed from the inside end g of its edge towards the outside end o,
+ *         t = d_g / (d_g - d_o),   (x, y, z, w) = fma(t, o - g, g)     (z = 0 exactly on the near plane),
+ *     with d the signed distance to the plane, so that the two triangles sharing the edge get the same point; when the
+ *     inside end is inside only by the first rule (d_g <= 0) no point is produced.
+ * The convex polygon of projectable vertices that is left is drawn as a fan, under the id of the triangle it came from. */
 static int g_near_clip = 0;
 SRO_API void sro_set_near_clip(int on) { g_near_clip = on; }
 
-/* returns the number of polygon vertices (0: nothing to draw), or -1 if the triangle cannot be clipped this way
- * (an unprojectable vertex in front of the near plane, or a cut point that cannot be projected): dropped and counted */
-static int near_clip_polygon(const float* c0, const float* c1, const float* c2, const screen_vertex* s0, const screen_vertex* s1,
-                             const screen_vertex* s2, int W, int H, screen_vertex* out /* [4] */)
+#define CLIP_MAX_VERTICES 8 /* 3 + one per plane */
+typedef struct { float c[4]; screen_vertex sv; int original; } clip_vertex; /* original: a projectable vertex of the triangle, sv valid */
+
+static float clip_plane_distance(int plane, const float* c, float kx, float ky)
 {
+    switch (plane) {
+    case 0: return c[2];
+    case 1: return kx * c[3] - c[0];
+    case 2: return kx * c[3] + c[0];
+    case 3: return ky * c[3] - c[1];
+    default: return ky * c[3] + c[1];
+    }
+}
+
+/* returns the number of polygon vertices written to out[CLIP_MAX_VERTICES] (0: nothing to draw), or -1 when a vertex that
+ * is left cannot be projected (a degenerate projection): the triangle is dropped and counted */
+static int near_clip_polygon(const float* c0, const float* c1, const float* c2, const screen_vertex* s0, const screen_vertex* s1,
+                             const screen_vertex* s2, int W, int H, screen_vertex* out)
+{
+    clip_vertex A[CLIP_MAX_VERTICES], B[CLIP_MAX_VERTICES];
+    clip_vertex *src = A, *dst = B;
     const float* c[3] = { c0, c1, c2 };
     const screen_vertex* sv[3] = { s0, s1, s2 };
-    int n = 0;
+    int n = 3;
     for (int i = 0; i < 3; ++i) {
-        int j = i == 2 ? 0 : i + 1;
-        int good_i = sv[i]->rw != 0.0f, good_j = sv[j]->rw != 0.0f;
-        if (good_i) out[n++] = *sv[i];
-        if (good_i == good_j) continue;
-        const float* g = good_i ? c[i] : c[j];
-        const float* o = good_i ? c[j] : c[i];
-        if (!(o[2] < 0.0f)) return -1;
-        if (!(g[2] > 0.0f)) continue;
-        float t = g[2] / (g[2] - o[2]);
-        float cut[4] = { fmaf(t, o[0] - g[0], g[0]), fmaf(t, o[1] - g[1], g[1]), 0.0f, fmaf(t, o[3] - g[3], g[3]) };
-        project_clip(cut, W, H, &out[n]);
-        if (out[n].rw == 0.0f) return -1;
-        ++n;
+        memcpy(src[i].c, c[i], 16);
+        src[i].sv = *sv[i];
+        src[i].original = sv[i]->rw != 0.0f;
     }
-    return n < 3 ? 0 : n;
+    const float kx = 524288.0f / ((float)W * 0.5f), ky = 524288.0f / ((float)H * 0.5f);
+    for (int plane = 0; plane < 5 && n >= 3; ++plane) {
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const clip_vertex* a = &src[i];
+            const clip_vertex* b = &src[i + 1 == n ? 0 : i + 1];
+            float da = clip_plane_distance(plane, a->c, kx, ky), db = clip_plane_distance(plane, b->c, kx, ky);
+            int in_a = a->original || da >= 0.0f, in_b = b->original || db >= 0.0f;
+            if (in_a) dst[m++] = *a;
+            if (in_a == in_b) continue;
+            const clip_vertex* g = in_a ? a : b;
+            const clip_vertex* o = in_a ? b : a;
+            float dg = in_a ? da : db, dout = in_a ? db : da;
+            if (!(dg > 0.0f) || !(dout < 0.0f)) continue;
+            float t = dg / (dg - dout);
+            clip_vertex* cut = &dst[m++];
+            for (int k = 0; k < 4; ++k) cut->c[k] = fmaf(t, o->c[k] - g->c[k], g->c[k]);
+            if (plane == 0) cut->c[2] = 0.0f;
+            cut->original = 0;
+        }
+        clip_vertex* tmp = src; src = dst; dst = tmp;
+        n = m;
+    }
+    if (n < 3) return 0;
+    for (int i = 0; i < n; ++i) {
+        if (src[i].original) out[i] = src[i].sv;
+        else project_clip(src[i].c, W, H, &out[i]);
+        if (out[i].rw == 0.0f) return -1;
+    }
+    return n;
 }
 
 typedef struct {
@@ -385,7 +423,7 @@ static void raster_band(const screen_vertex* sv, const float* clip /* 4 per vert
         if (!setup_triangle(v0, v1, v2, &t, &needs_clip)) {
             if (!needs_clip) continue;
             if (!g_near_clip) { if (st) st->tris_culled_clip++; continue; }
-            screen_vertex poly[4];
+            screen_vertex poly[CLIP_MAX_VERTICES];
             int n = near_clip_polygon(clip + 4*(size_t)i0, clip + 4*(size_t)i1, clip + 4*(size_t)i2, v0, v1, v2, vt->W, vt->H, poly);
             if (n < 0) { if (st) st->tris_culled_clip++; continue; }
             if (n >= 3 && st) st->tris_clipped++;

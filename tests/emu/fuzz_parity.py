@@ -34,6 +34,10 @@ def random_scene(rng):
         pts = np.cumsum(rng.normal(size=(n + 2, 3)) * 0.15, axis=0)
         pos = np.stack([pts[:-2], pts[1:-1], pts[2:]], axis=1)
         pos[1::2] = pos[1::2, ::-1]
+    if rng.integers(0, 6) == 0:   # a few enormous triangles through the scene: vertices far outside the guard band, behind the eye, ...
+        k = int(rng.integers(1, 4))
+        pos = np.concatenate([pos, rng.uniform(-1.5, 1.5, size=(k, 1, 3)) + rng.uniform(-1, 1, size=(k, 3, 3)) * 10.0 ** rng.uniform(2, 4)])
+        n += k
     pos = pos.astype(np.float32)
     dup = rng.integers(0, n, size=max(1, n // 9))
     pos[dup] = pos[(dup + 1) % n]                       # exact duplicates: depth ties

@@ -85,9 +85,7 @@ def test_huge_triangles_cover_many_tiles(sr, oracle, device):
 
 def test_near_plane_crossing_is_dropped_and_counted(sr, oracle, device):
     clipping = "near_clip" in os.environ.get("SR_VARIANT", "")
-    # reaches behind the eye.  (At +-500 the cut points at the near plane lie outside the guard band and the clipper of
-    # the near_clip variant gives the triangles up as well -- covered by test_near_plane_clipper.)
-    verts, idx = sr.scene.screen_quad(z=0.0, half=50.0 if clipping else 500.0)
+    verts, idx = sr.scene.screen_quad(z=0.0, half=500.0)   # reaches behind the eye
     small, sidx = sr.scene.uv_sphere(16, 16)
     v = np.concatenate([verts, small]); i = np.concatenate([idx, sidx + 4]).astype(np.uint32)
     ubo = sr.scene.default_camera_ubo(320, 240)
@@ -298,7 +296,7 @@ def test_near_plane_clipper(sr, oracle, samples):
     plane and drawn, as the fixed-function clipper of the reference's pipeline does, instead of dropped.  A ground
     quad that passes under and behind the camera, and a sphere seen from inside with the eye close to its surface
     (dozens of triangles reach from behind the eye to beyond the near plane, sharing their cut edges): visibility equals the oracle's
-    clipper bit for bit, colour to the usual bar, in a two-view draw; then a clip list of 8 entries, where the
+    clipper bit for bit, colour to the usual bar, in a three-view draw; then a clip list of 8 entries, where the
     triangles that find no room are dropped and counted."""
     import math
     if "near_clip" not in os.environ.get("SR_VARIANT", ""):
@@ -306,7 +304,7 @@ def test_near_plane_clipper(sr, oracle, samples):
     W, H = 256, 160
     images = sr.scene.material_textures(64, seed=4)
     ground = np.zeros((4, 8), np.float32)
-    ground[:, :3] = [[-50, -50, 0], [50, -50, 0], [50, 50, 0], [-50, 50, 0]]
+    ground[:, :3] = [[-2000, -2000, 0], [2000, -2000, 0], [2000, 2000, 0], [-2000, 2000, 0]]   # its cuts at the near plane leave the guard band
     ground[:, 5] = 1.0
     ground[:, 6:8] = ground[:, :2] * 0.1
     ball, ball_idx = _inward_sphere(sr, 32, 20, 1.0)     # triangles larger than the near distance: some span it

@@ -107,7 +107,7 @@ struct sr_device_t {
     float* d_thresh = nullptr;   // 255 (+1 pad)
     // scratch reused by every draw on this device (in-order on `stream`)
     DeviceBuffer screen, tile_count, tile_offset, survivors, survivor_count, refs, views, counters;
-    DeviceBuffer clip;           // kVariantNearClip: [state: 4 words][entries: capacity x 8 bytes][records: 2 x capacity x 48 bytes]
+    DeviceBuffer clip;           // kVariantNearClip: [state: 4 words][entries: capacity x 8 bytes][records: kClipMaxPieces x capacity x 48 bytes]
     uint32_t clip_capacity = 65536;   // triangles per pass that can be clipped; more are dropped and counted
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
@@ -332,7 +332,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * setup_block_records() * sizeof(BinRecord)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
     const bool near_clip = (dev->variants & kVariantNearClip) && m->d_pos4;
-    if (near_clip) SR_HIP(dev->clip.ensure(16 + (size_t)dev->clip_capacity * (sizeof(uint2) + 2 * sizeof(ClipRecord))));
+    if (near_clip) SR_HIP(dev->clip.ensure(16 + (size_t)dev->clip_capacity * (sizeof(uint2) + kClipMaxPieces * sizeof(ClipRecord))));
     const bool culling = (dev->variants & kVariantClusterCull) && m->d_clusters && m->d_pos4 && tg->cull_views.size() == n_views;
     const size_t view_bytes = (size_t)n_views * (sizeof(ViewXform) + (culling ? sizeof(ViewCull) : 0));   // [transforms][cull constants]
     SR_HIP(dev->views.ensure(view_bytes));

@@ -320,13 +320,9 @@ __device__ inline bool cluster_is_invisible(const ClusterRec& cl, const ViewCull
 // be projected (w <= 0, or outside the guard band) is dropped and counted.  The fixed-function clipper of the
 // reference's pipeline keeps the part of such a triangle inside 0 <= z_c <= w_c (src/main.cpp:559-600 leaves depth
 // clipping on); with the variant on, the fused set-up kernel lists these triangles and two small kernels draw them:
-//   * near_clip_kernel cuts every edge that joins a projectable vertex g in front of the near plane (z_c > 0) and
-//     an unprojectable vertex o (which must lie behind it, z_c < 0) at z_c = 0:
-//         t = z_g / (z_g - z_o),   (x, y, w) = fma(t, o - g, g),   z = 0,
-//     always from g towards o, so that both triangles sharing the edge get the same point.  Edges between
-//     projectable vertices stay as they are -- identical to the neighbouring triangle's edge; what lies beyond the
-//     near plane on them is removed per sample by the depth range test.  The polygon of 3 or 4 projectable vertices
-//     becomes one or two records of window-space vertices;
+//   * near_clip_kernel clips each of them in clip space against the near plane and four side planes inside the guard
+//     band (near_clip_polygon below) and writes the convex polygon that is left as up to kClipMaxPieces records of
+//     window-space vertices (a fan);
 //   * clipped_raster_kernel resolves the records into the visibility buffer under the id of the triangle they came
 //     from, with the edge functions, depth expression and 64-bit min of every other path.
 // The shading pass recognises such a triangle by its unprojectable vertex and interpolates from clip-space
@@ -340,7 +336,7 @@ struct ClipList {
     uint2* entries;            // (view inside the pass, triangle); null: variant off
     uint32_t* count;           // entries appended by set-up (may exceed capacity: the excess is counted as dropped)
     uint32_t capacity;
-    ClipRecord* records;       // [2 * capacity]
+    ClipRecord* records;       // [kClipMaxPieces * capacity]
     uint32_t* state;           // [0] records written, [1] triangles clipped
 };
 
@@ -366,28 +362,74 @@ __device__ inline ScreenVertex project_clip_coords(const float* clip, int W, int
     return sv;
 }
 
-// number of polygon vertices written to out[4] (0: nothing to draw), or -1 when the triangle cannot be clipped this
-// way (an unprojectable vertex in front of the near plane, or a cut point that cannot be projected)
+// The clipper proper.  The triangle is clipped in clip space against the near plane (z >= 0) and then against four
+// side planes |x| <= K_x w, |y| <= K_y w that keep every cut point 2^19 pixels or less from the frame (inside the
+// guard band).  Two rules make the result fit the triangles around it:
+//   * a projectable vertex of the triangle counts as inside every plane, whatever its coordinates: the edges between
+//     two such vertices are never cut and stay bit-identical to the neighbouring triangles' edges (on the near plane
+//     the depth range test removes, per sample, what lies beyond it; the side planes are outside the guard band such
+//     a vertex is inside of);
+//   * a cut point is always computed from the inside end g of its edge towards the outside end o,
+//         t = d_g / (d_g - d_o),   (x, y, z, w) = fma(t, o - g, g)     (z = 0 exactly on the near plane),
+//     with d the signed distance to the plane, so both triangles that share the edge get the same point; when the
+//     inside end is inside only by the first rule (d_g <= 0) no point is produced -- the polygon goes on from g.
+// out: up to kClipMaxVertices window-space vertices of a convex polygon, to be drawn as a fan.  Returns their number
+// (0: nothing to draw), or -1 when a vertex that is left cannot be projected (a degenerate projection): dropped and counted.
+constexpr int kClipMaxVertices = 8;     // 3 + one per plane
+constexpr int kClipMaxPieces = kClipMaxVertices - 2;
+struct ClipVertex { float c[4]; ScreenVertex sv; bool original; };   // original: a projectable vertex of the triangle, sv valid
+
+__device__ inline float clip_plane_distance(int plane, const float* c, float kx, float ky)
+{
+    switch (plane) {
+    case 0: return c[2];
+    case 1: return kx * c[3] - c[0];
+    case 2: return kx * c[3] + c[0];
+    case 3: return ky * c[3] - c[1];
+    default: return ky * c[3] + c[1];
+    }
+}
+
 __device__ inline int near_clip_polygon(const float (*c)[4] /* clip coordinates of the 3 vertices */, const ScreenVertex* sv /* [3] */, int W, int H, ScreenVertex* out)
 {
-    int n = 0;
-#pragma unroll
+    ClipVertex A[kClipMaxVertices], B[kClipMaxVertices];
+    ClipVertex* src = A;
+    ClipVertex* dst = B;
+    int n = 3;
     for (int i = 0; i < 3; ++i) {
-        const int j = i == 2 ? 0 : i + 1;
-        const bool good_i = sv[i].rw != 0.0f, good_j = sv[j].rw != 0.0f;
-        if (good_i) out[n++] = sv[i];
-        if (good_i == good_j) continue;
-        const float* g = good_i ? c[i] : c[j];
-        const float* o = good_i ? c[j] : c[i];
-        if (!(o[2] < 0.0f)) return -1;
-        if (!(g[2] > 0.0f)) continue;
-        const float t = g[2] / (g[2] - o[2]);
-        const float cut[4] = { fmaf(t, o[0] - g[0], g[0]), fmaf(t, o[1] - g[1], g[1]), 0.0f, fmaf(t, o[3] - g[3], g[3]) };
-        out[n] = project_clip_coords(cut, W, H);
-        if (out[n].rw == 0.0f) return -1;
-        ++n;
+        for (int k = 0; k < 4; ++k) src[i].c[k] = c[i][k];
+        src[i].sv = sv[i];
+        src[i].original = sv[i].rw != 0.0f;
     }
-    return n < 3 ? 0 : n;
+    const float kx = 524288.0f / ((float)W * 0.5f), ky = 524288.0f / ((float)H * 0.5f);
+    for (int plane = 0; plane < 5 && n >= 3; ++plane) {
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const ClipVertex& a = src[i];
+            const ClipVertex& b = src[i + 1 == n ? 0 : i + 1];
+            const float da = clip_plane_distance(plane, a.c, kx, ky), db = clip_plane_distance(plane, b.c, kx, ky);
+            const bool in_a = a.original || da >= 0.0f, in_b = b.original || db >= 0.0f;
+            if (in_a) dst[m++] = a;
+            if (in_a == in_b) continue;
+            const ClipVertex& g = in_a ? a : b;
+            const ClipVertex& o = in_a ? b : a;
+            const float dg = in_a ? da : db, dout = in_a ? db : da;
+            if (!(dg > 0.0f) || !(dout < 0.0f)) continue;
+            const float t = dg / (dg - dout);
+            ClipVertex& cut = dst[m++];
+            for (int k = 0; k < 4; ++k) cut.c[k] = fmaf(t, o.c[k] - g.c[k], g.c[k]);
+            if (plane == 0) cut.c[2] = 0.0f;
+            cut.original = false;
+        }
+        ClipVertex* tmp = src; src = dst; dst = tmp;
+        n = m;
+    }
+    if (n < 3) return 0;
+    for (int i = 0; i < n; ++i) {
+        out[i] = src[i].original ? src[i].sv : project_clip_coords(src[i].c, W, H);
+        if (out[i].rw == 0.0f) return -1;
+    }
+    return n;
 }
 
 }  // namespace sr

@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void sparse_tail_kernel(const uint32_t* __rest
 
 // =================================================================================================
 // near-plane clipping (pipeline variant, see sr_device.h): one work-item per listed triangle cuts it
-// and writes one or two records of window-space vertices ...
+// and writes a record of window-space vertices for every piece ...
 // =================================================================================================
 __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, const float4* __restrict__ pos4,
                                                         const ViewXform* __restrict__ views, FrameGeom g, ClipList clip, uint32_t* __restrict__ counters)
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restri
             const float4 q = pos4[idx[3 * (size_t)tri + k]];
             sv[k] = project_vertex(views[view], q.x, q.y, q.z, g.W, g.H, c[k]);
         }
-        ScreenVertex poly[4];
+        ScreenVertex poly[kClipMaxVertices];
         const int np = near_clip_polygon(c, sv, g.W, g.H, poly);
         if (np < 0) { atomicAdd(&counters[2], 1u); continue; }   // cannot be clipped against the near plane: dropped and counted
         if (np == 0) continue;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restri
             r.X[1] = poly[k - 1].X; r.Y[1] = poly[k - 1].Y; r.z[1] = poly[k - 1].z;
             r.X[2] = poly[k].X; r.Y[2] = poly[k].Y; r.z[2] = poly[k].z;
             r.tri = tri; r.view = view; r.pad = 0u;
-            clip.records[atomicAdd(&clip.state[0], 1u)] = r;   // at most two per entry: the array holds 2 * capacity
+            clip.records[atomicAdd(&clip.state[0], 1u)] = r;   // at most kClipMaxPieces per entry: the array holds that many times the capacity
         }
     }
 }
@@ -776,7 +776,7 @@ template <int S>
 __global__ __launch_bounds__(256) void clipped_raster_kernel(ClipList clip, FrameGeom g, unsigned long long* __restrict__ vis, uint32_t view0, DirtyMap dirty,
                                                              uint32_t* __restrict__ host_counters)
 {
-    const uint32_t n = min(clip.state[0], 2u * clip.capacity);
+    const uint32_t n = min(clip.state[0], (uint32_t)kClipMaxPieces * clip.capacity);
     if (blockIdx.x == 0u && threadIdx.x == 0u) host_counters[6] = clip.state[1];   // triangles clipped in this pass, for the host
     const uint32_t lane = lane_id();
     const uint32_t waves_total = gridDim.x * 4u, first = blockIdx.x * 4u + (threadIdx.x >> 6);
