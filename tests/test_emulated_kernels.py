@@ -182,6 +182,15 @@ def test_differential_fuzzing_against_the_oracle():
         assert proc.returncode == 0 and "ok: seeds" in out, f"variant '{v}':\n{out[-3000:]}"
 
 
+def test_benchmark_and_smoke_scripts_run_end_to_end():
+    """tests/emu/rehearse.py: bench.py (two small workloads, one process) and __graft_entry__.smoke() against the CPU build
+    of the kernels -- the scripts the round-end driver runs on the GPU box still produce their JSON line and their
+    oracle comparison with the current library."""
+    build_emulation_library()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "rehearse.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("bench ok:") == 2 and r.stdout.strip().endswith("smoke ok"), r.stdout[-3000:]
+
+
 def test_file_readers_survive_mutated_files():
     """tests/emu/fuzz_files.py and fuzz_png.py, a short run each: the PNG and glTF readers under
     AddressSanitizer / UndefinedBehaviorSanitizer on mutated files."""
