@@ -121,7 +121,7 @@ SR_API int sr_texture_read_level(sr_device dev, sr_texture tex, int level, void*
  *
  * sr_texture_create_from_file replaces create_texture_from_file, src/texture.hpp:20 / src/texture.cpp:273-291:
  * the file is expanded to 8-bit RGBA as stbi_load(path, ..., STBI_rgb_alpha) does (gray -> R=G=B, no alpha
- * -> 255, 16-bit -> high byte), then handed to sr_texture_create_rgba8_srgb.  PNG (no interlace) and
+ * -> 255, 16-bit -> high byte), then handed to sr_texture_create_rgba8_srgb.  PNG and
  * Huffman-coded 8-bit JPEG (baseline and progressive; gray, YCbCr, RGB).  JPEG decoders differ in the last bit
  * of the inverse DCT, the chroma filter and the colour conversion: the default follows stb_image's arithmetic,
  * the environment variable SR_JPEG_DECODER=libjpeg selects libjpeg's. */

@@ -23,6 +23,10 @@ for (ct, d) in [(0,1),(0,8),(0,16),(2,8),(3,2),(3,8),(4,8),(6,8),(6,16)]:
     p = out / f'seed_{ct}_{d}.png'
     F.write_png(str(p), F._pack_rows(samples, d), w, h, ct, d, filters=[0,1,2,3,4], plte=list(range(48)) if ct==3 else None, trns=[1,2,3] if ct==3 else None)
     seeds.append(p)
+    if d in (2, 8):   # the same kind once more with Adam7 interlacing
+        p = out / f'seed_{ct}_{d}_i.png'
+        F.write_png(str(p), None, w, h, ct, d, filters=[4,1,3], plte=list(range(48)) if ct==3 else None, trns=[1,2,3] if ct==3 else None, interlaced_samples=samples)
+        seeds.append(p)
 for n, kw in enumerate([dict(subsampling=2), dict(subsampling=1, progressive=True), dict(subsampling=0, progressive=True, optimize=True), dict(restart_marker_blocks=2)]):
     p = out / f'seed_{n}.jpg'
     F._test_picture(37, 21, n, gray=(n == 3)).save(str(p), 'JPEG', quality=85, **kw)

@@ -35,10 +35,8 @@ def _paeth(a, b, c):
     return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
 
 
-def write_png(path, rows, width, height, ctype, depth, filters, plte=None, trns=None):
-    """rows: list of bytes objects (already packed scan lines); filters: one filter type per row."""
-    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
-    bpp = max(channels * depth // 8, 1)
+def _filter_rows(rows, bpp, filters):
+    """Packed scan lines -> filtered stream (filter type byte + residues per line)."""
     raw = bytearray()
     prev = bytes(len(rows[0]))
     for y, row in enumerate(rows):
@@ -52,7 +50,28 @@ def write_png(path, rows, width, height, ctype, depth, filters, plte=None, trns=
             out[i] = (v - pred) & 255
         raw += bytes([f]) + out
         prev = row
-    data = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, 0))
+    return raw
+
+
+ADAM7 = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]   # x0, y0, dx, dy
+
+
+def write_png(path, rows, width, height, ctype, depth, filters, plte=None, trns=None, interlaced_samples=None):
+    """rows: list of bytes objects (already packed scan lines); filters: one filter type per row.
+    interlaced_samples: instead of rows, the (height, width*channels) array of raw samples, written as the seven
+    passes of Adam7 interlacing."""
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(channels * depth // 8, 1)
+    if interlaced_samples is None:
+        raw = _filter_rows(rows, bpp, filters)
+    else:
+        raw = bytearray()
+        px = np.asarray(interlaced_samples).reshape(height, width, channels)
+        for x0, y0, dx, dy in ADAM7:
+            sub = px[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += _filter_rows(_pack_rows(sub.reshape(sub.shape[0], -1), depth), bpp, filters)
+    data = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, 0 if interlaced_samples is None else 1))
     if plte is not None:
         data += _chunk(b"PLTE", bytes(plte))
     if trns is not None:
@@ -110,6 +129,26 @@ def test_png_matches_pillow(sr, tmp_path, ctype, depth):
     else:
         exp = np.asarray(Image.open(path).convert("RGBA"))
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("ctype,depth", [(0, 1), (0, 4), (0, 16), (2, 8), (3, 2), (3, 8), (4, 8), (6, 8), (6, 16)])
+def test_interlaced_png_matches_the_plain_one(sr, tmp_path, ctype, depth):
+    """Adam7: the same samples written plain and interlaced decode to the same pixels (and to what Pillow reads), for
+    sizes down to 1 x 1, where most of the seven passes are empty."""
+    from PIL import Image
+    rng = np.random.default_rng(ctype * 100 + depth + 7)
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    for w, h in [(37, 23), (1, 1), (3, 2), (5, 9), (8, 8), (2, 5)]:
+        samples = rng.integers(0, 1 << depth, size=(h, w * channels))
+        plte = rng.integers(0, 256, size=3 * (1 << depth)).tolist() if ctype == 3 else None
+        trns = rng.integers(0, 256, size=(1 << depth) // 2 + 1).tolist() if ctype == 3 else None
+        plain, laced = str(tmp_path / "plain.png"), str(tmp_path / "laced.png")
+        write_png(plain, _pack_rows(samples, depth), w, h, ctype, depth, filters=[4, 0, 3], plte=plte, trns=trns)
+        write_png(laced, None, w, h, ctype, depth, filters=[1, 4, 2, 3, 0], plte=plte, trns=trns, interlaced_samples=samples)
+        got = sr.read_image(laced)
+        assert got.shape == (h, w, 4) and np.array_equal(got, sr.read_image(plain)), (w, h)
+        if depth != 16:
+            assert np.array_equal(got, np.asarray(Image.open(laced).convert("RGBA"))), (w, h)
 
 
 def test_png_colour_key_and_errors(sr, tmp_path):

@@ -3,7 +3,7 @@
 //   Model::load              (src/model.cpp:81-98):     Assimp ReadFile(Triangulate | FlipUVs), one StaticMesh per
 //                                                        mesh found by a depth-first walk of the nodes
 // Neither stb nor Assimp exists here, so this file reads the formats the reference's data directory
-// uses itself: PNG (non-interlaced, every colour type and bit depth), JPEG (sr_jpeg.cpp) and glTF 2.0 (.gltf
+// uses itself: PNG (every colour type and bit depth, Adam7 interlacing), JPEG (sr_jpeg.cpp) and glTF 2.0 (.gltf
 // with data: or file buffers, .glb).  Pure CPU code; nothing here touches the GPU.
 #include "sr_assets.h"
 
@@ -72,7 +72,7 @@ bool decode_png(const uint8_t* data, size_t size, Image& img, std::string& err)
     }
     if (ctype < 0 || !end) { err = "PNG without IHDR or IEND"; return false; }
     if (w == 0 || h == 0 || w > 32768 || h > 32768) { err = "PNG size out of range"; return false; }
-    if (interlace != 0) { err = "interlaced PNG is not supported"; return false; }
+    if (interlace > 1) { err = "unknown PNG interlace method"; return false; }
     int channels;
     switch (ctype) {
     case 0: channels = 1; break;
@@ -87,29 +87,27 @@ bool decode_png(const uint8_t* data, size_t size, Image& img, std::string& err)
                                      : (depth == 8 || depth == 16);
     if (!depth_ok) { err = "bit depth not allowed for this PNG colour type"; return false; }
     if (ctype == 3 && plte.size() < 3) { err = "palette PNG without PLTE"; return false; }
-    const size_t bits_pp = (size_t)channels * depth, stride = ((size_t)w * bits_pp + 7) / 8, bpp = std::max<size_t>(bits_pp / 8, 1);
+    const size_t bits_pp = (size_t)channels * depth, bpp = std::max<size_t>(bits_pp / 8, 1);
+    // the image is stored as one pass, or as the seven passes of Adam7 interlacing: sub-images of every 8th, 4th, 2nd
+    // pixel, each with its own filtered scan lines
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const int n_passes = interlace ? 7 : 1;
+    size_t raw_size = 0;
+    for (int p = 0; p < n_passes; ++p) {
+        const Pass& ps = interlace ? adam7[p] : whole;
+        const size_t pw = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0, ph = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+        if (pw && ph) raw_size += ((pw * bits_pp + 7) / 8 + 1) * ph;
+    }
     // deflate cannot expand by more than about 1032:1: a header that promises more than the data can hold is refused
     // before anything of that size is allocated
-    if ((stride + 1) * (size_t)h > idat.size() * 1032 + 65536) { err = "PNG image data is too short for the size in its header"; return false; }
-    std::vector<uint8_t> raw((stride + 1) * h);
+    if (raw_size > idat.size() * 1032 + 65536) { err = "PNG image data is too short for the size in its header"; return false; }
+    std::vector<uint8_t> raw(raw_size);
     uLongf raw_len = (uLongf)raw.size();
     const int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
     if (zr != Z_OK || raw_len != raw.size()) { err = "PNG image data does not inflate to the expected size"; return false; }
-    // undo the scan-line filters in place (row r starts at r*(stride+1)+1)
-    std::vector<uint8_t> zero(stride, 0);
-    for (uint32_t y = 0; y < h; ++y) {
-        uint8_t* cur = raw.data() + (size_t)y * (stride + 1) + 1;
-        const uint8_t* up = y ? cur - (stride + 1) : zero.data();
-        switch (cur[-1]) {
-        case 0: break;
-        case 1: for (size_t i = bpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
-        case 2: for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]); break;
-        case 3: for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + (((i >= bpp ? cur[i - bpp] : 0) + up[i]) >> 1)); break;
-        case 4: for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + paeth(i >= bpp ? cur[i - bpp] : 0, up[i], i >= bpp ? up[i - bpp] : 0)); break;
-        default: err = "unknown PNG filter type"; return false;
-        }
-    }
-    // expand to 8-bit RGBA the way stbi_load(..., STBI_rgb_alpha) does: gray -> r=g=b, no alpha -> 255,
+    // expansion to 8-bit RGBA the way stbi_load(..., STBI_rgb_alpha) does: gray -> r=g=b, no alpha -> 255,
     // 16-bit -> high byte, low bit depths scaled to 0..255, palette looked up, tRNS applied
     img.width = (int)w; img.height = (int)h;
     img.rgba.assign((size_t)w * h * 4, 255);
@@ -124,27 +122,49 @@ bool decode_png(const uint8_t* data, size_t size, Image& img, std::string& err)
     uint32_t key[3] = {0, 0, 0};
     const bool has_key = (ctype == 0 && trns.size() >= 2) || (ctype == 2 && trns.size() >= 6);
     if (has_key) for (int c = 0; c < (ctype == 0 ? 1 : 3); ++c) key[c] = ((uint32_t)trns[2 * c] << 8) | trns[2 * c + 1];
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t* row = raw.data() + (size_t)y * (stride + 1) + 1;
-        uint8_t* o = img.rgba.data() + (size_t)y * w * 4;
-        for (uint32_t x = 0; x < w; ++x, o += 4) {
-            if (ctype == 3) {
-                const uint32_t i = sample(row, x);
-                if (3 * (size_t)i + 2 >= plte.size()) { err = "PNG palette index out of range"; return false; }
-                o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
-                o[3] = i < trns.size() ? trns[i] : 255;
-            } else if (ctype == 0 || ctype == 4) {
-                const uint32_t g = sample(row, (size_t)x * channels);
-                o[0] = o[1] = o[2] = to8(g);
-                if (ctype == 4) o[3] = to8(sample(row, (size_t)x * 2 + 1));
-                else if (has_key && g == key[0]) o[3] = 0;
-            } else {
-                const uint32_t r = sample(row, (size_t)x * channels), g = sample(row, (size_t)x * channels + 1), b = sample(row, (size_t)x * channels + 2);
-                o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
-                if (ctype == 6) o[3] = to8(sample(row, (size_t)x * 4 + 3));
-                else if (has_key && r == key[0] && g == key[1] && b == key[2]) o[3] = 0;
+    uint8_t* pass_data = raw.data();
+    for (int p = 0; p < n_passes; ++p) {
+        const Pass& ps = interlace ? adam7[p] : whole;
+        const size_t pw = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0, ph = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+        if (!pw || !ph) continue;
+        const size_t stride = (pw * bits_pp + 7) / 8;
+        // undo the scan-line filters in place (row r of the pass starts at r*(stride+1)+1)
+        std::vector<uint8_t> zero(stride, 0);
+        for (size_t y = 0; y < ph; ++y) {
+            uint8_t* cur = pass_data + y * (stride + 1) + 1;
+            const uint8_t* up = y ? cur - (stride + 1) : zero.data();
+            switch (cur[-1]) {
+            case 0: break;
+            case 1: for (size_t i = bpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
+            case 2: for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]); break;
+            case 3: for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + (((i >= bpp ? cur[i - bpp] : 0) + up[i]) >> 1)); break;
+            case 4: for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + paeth(i >= bpp ? cur[i - bpp] : 0, up[i], i >= bpp ? up[i - bpp] : 0)); break;
+            default: err = "unknown PNG filter type"; return false;
             }
         }
+        for (size_t y = 0; y < ph; ++y) {
+            const uint8_t* row = pass_data + y * (stride + 1) + 1;
+            for (size_t x = 0; x < pw; ++x) {
+                uint8_t* o = img.rgba.data() + (((size_t)ps.y0 + y * ps.dy) * w + ps.x0 + x * ps.dx) * 4;
+                if (ctype == 3) {
+                    const uint32_t i = sample(row, x);
+                    if (3 * (size_t)i + 2 >= plte.size()) { err = "PNG palette index out of range"; return false; }
+                    o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
+                    o[3] = i < trns.size() ? trns[i] : 255;
+                } else if (ctype == 0 || ctype == 4) {
+                    const uint32_t g = sample(row, x * channels);
+                    o[0] = o[1] = o[2] = to8(g);
+                    if (ctype == 4) o[3] = to8(sample(row, x * 2 + 1));
+                    else if (has_key && g == key[0]) o[3] = 0;
+                } else {
+                    const uint32_t r = sample(row, x * channels), g = sample(row, x * channels + 1), b = sample(row, x * channels + 2);
+                    o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
+                    if (ctype == 6) o[3] = to8(sample(row, x * 4 + 3));
+                    else if (has_key && r == key[0] && g == key[1] && b == key[2]) o[3] = 0;
+                }
+            }
+        }
+        pass_data += (stride + 1) * ph;
     }
     return true;
 }
