@@ -904,7 +904,8 @@ int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_block
         std::memcpy(x.model, u, 64);
         mat4_mul_mat4_host(u + 32, u + 16, x.pv);   // proj * view
         std::memcpy(x.cam, u + 48, 12);
-        x.pad = 0.0f;
+        static const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        x.model_is_identity = std::memcmp(x.model, identity, 64) == 0 ? 1.0f : 0.0f;   // lets the variants' kernels skip the product with it
     }
     target->cull_views.clear();
     if (dev->variants & kVariantClusterCull)

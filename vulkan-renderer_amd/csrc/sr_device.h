@@ -32,7 +32,7 @@ struct ViewXform {       // one per view, derived on the host from the reference
     float model[16];     // column-major
     float pv[16];        // proj * view, column-major
     float cam[3];
-    float pad;
+    float model_is_identity;   // 1 when model is exactly the identity matrix (every configuration of the reference, src/main.cpp:991), else 0
 };
 
 struct ScreenVertex {    // 16 bytes; rw == 0 marks a vertex that cannot be projected
@@ -360,6 +360,24 @@ __device__ inline ScreenVertex project_clip_coords(const float* clip, int W, int
     sv.z = zd;
     sv.rw = rw;
     return sv;
+}
+
+// model * (p, 1) with a shortcut for the identity: the general product returns p + 0 then, bit for bit for finite
+// positions, at a third of the cost of a vertex projection.  Used by the geometry kernels of the pipeline variants,
+// which project every vertex once per triangle corner.  (The shading kernels keep the general product: the branch
+// costs them eight registers and a wave of occupancy.)
+__device__ inline void world_position(const ViewXform& vx, float px, float py, float pz, float* wp)
+{
+    if (vx.model_is_identity != 0.0f) { wp[0] = px + 0.0f; wp[1] = py + 0.0f; wp[2] = pz + 0.0f; wp[3] = 1.0f; }
+    else mat4_mul_vec4(vx.model, px, py, pz, 1.0f, wp);
+}
+// project_vertex with that shortcut: the same clip coordinates and window-space record
+__device__ inline ScreenVertex project_vertex_short(const ViewXform& vx, float px, float py, float pz, int W, int H, float* clip)
+{
+    float wp[4];
+    world_position(vx, px, py, pz, wp);
+    mat4_mul_vec4(vx.pv, wp[0], wp[1], wp[2], 1.0f, clip);
+    return project_clip_coords(clip, W, H);
 }
 
 // The clipper proper.  The triangle is clipped in clip space against the near plane (z >= 0) and then against four

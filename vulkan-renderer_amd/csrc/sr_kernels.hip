@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restri
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float4 q = pos4[idx[3 * (size_t)tri + k]];
-            sv[k] = project_vertex(views[view], q.x, q.y, q.z, g.W, g.H, c[k]);
+            sv[k] = project_vertex_short(views[view], q.x, q.y, q.z, g.W, g.H, c[k]);
         }
         ScreenVertex poly[kClipMaxVertices];
         const int np = near_clip_polygon(c, sv, g.W, g.H, poly);
