@@ -162,6 +162,58 @@ def test_unprojectable_triangles_are_dropped_and_counted(oracle):
     assert r["stats"]["tris_clip_culled"] == 0 and (r["tri"] == 0xFFFFFFFF).all()
 
 
+@pytest.mark.parametrize("half", [50.0, 5000.0])
+def test_near_plane_clipper_against_a_ray_cast(oracle, half):
+    """sro_set_near_clip: a ground plane that passes under and behind the camera (two triangles with a vertex behind the
+    eye; at +-5000 units their cuts at the near plane also leave the guard band and the side planes come in).  The
+    covered pixels are exactly those whose centre ray hits the plane inside the quad between the near and the far
+    plane, and the depth is the plane's; a quad cut short in front of the camera (one of its triangles needs no
+    clipping) gets the same colours."""
+    W, H = 320, 200
+    eye = np.array([0.3, -2.0, 1.0])
+
+    def quad(y0):
+        v = np.zeros((4, 8), np.float32)
+        v[:, :3] = [[-half, y0, 0], [half, y0, 0], [half, half, 0], [-half, half, 0]]
+        v[:, 5] = 1.0
+        v[:, 6:8] = v[:, :2] * 0.1
+        return v
+    idx = np.array([0, 1, 2, 0, 2, 3], np.uint32)
+    view, proj = scene.look_at(eye, (0.0, 3.0, 0.0), (0, 0, 1)), scene.perspective(math.radians(45.0), W / H, 0.1, 10.0)
+    ubo = scene.make_ubo(np.eye(4, dtype=np.float32), view, proj, eye)
+    tex = scene.material_textures(64, seed=1)
+    oracle.set_near_clip(False)
+    off = oracle.draw(ubo, quad(-half), idx, tex, W, H, 1, shade=False)
+    assert off["stats"]["tris_clip_culled"] == 2 and (off["tri"] == 0xFFFFFFFF).all()
+    oracle.set_near_clip(True)
+    try:
+        r = oracle.draw(ubo, quad(-half), idx, tex, W, H, 1, threads=4)
+        short = oracle.draw(ubo, quad(-1.0), idx, tex, W, H, 1, threads=4)
+    finally:
+        oracle.set_near_clip("near_clip" in os.environ.get("SR_VARIANT", ""))   # what the session's other tests expect
+    assert r["stats"]["tris_clipped"] == 2 and r["stats"]["tris_clip_culled"] == 0
+    # the same frame by ray casting, in double precision
+    pv = proj.astype(np.float64) @ view.astype(np.float64)
+    inv = np.linalg.inv(pv)
+    ys, xs = np.mgrid[0:H, 0:W]
+    nx, ny = (xs + 0.5 - W / 2) / (W / 2), (H / 2 - (ys + 0.5)) / (H / 2)
+
+    def unproject(z):
+        p = np.stack([nx, ny, np.full_like(nx, z), np.ones_like(nx)], -1) @ inv.T
+        return p[..., :3] / p[..., 3:4]
+    a, b = unproject(0.0), unproject(1.0)
+    t = a[..., 2] / (a[..., 2] - b[..., 2])
+    hit = a + t[..., None] * (b - a)
+    expected = (t >= 0) & (t <= 1) & (np.abs(hit[..., 0]) <= half) & (np.abs(hit[..., 1]) <= half)
+    got = r["tri"][..., 0] != 0xFFFFFFFF
+    assert expected.sum() > W * H // 2 and np.array_equal(got, expected)
+    clip = np.concatenate([hit, np.ones_like(hit[..., :1])], -1) @ pv.T
+    assert np.abs(r["depth"][..., 0][got] - (clip[..., 2] / clip[..., 3])[got]).max() < (1e-5 if half < 100 else 1e-4)
+    both = got & (short["tri"][..., 0] != 0xFFFFFFFF)
+    assert both.sum() > W * H // 2
+    assert np.abs(r["bgra"].astype(int) - short["bgra"].astype(int)).max(axis=-1)[both].max() <= 1
+
+
 def test_sphere_is_front_facing_from_outside(oracle):
     """The synthetic mesh must be counter-clockwise seen from outside: the hemisphere facing the
     default camera is drawn, and depth at the centre is the near pole of the unit sphere."""
