@@ -18,7 +18,8 @@ def pytest_configure(config):
 # one of the special paths should not hide the results of the basic ones.
 RUN_AFTER_THE_BASIC_PARITY_TESTS = ("test_target_is_reused_across_different_draws", "test_cluster_culling_never_drops_a_drawn_triangle",
                                     "test_model_and_textures_from_files", "test_tile_reference_list_grows_and_the_draw_is_repeated",
-                                    "test_more_distinct_tiles_than_a_binning_block_can_hash", "test_view_batch_split_into_passes", "test_near_plane_clipper")
+                                    "test_more_distinct_tiles_than_a_binning_block_can_hash", "test_view_batch_split_into_passes", "test_near_plane_clipper",
+                                    "test_fragments_exactly_on_the_far_plane")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -213,6 +213,7 @@ static inline float hipemu_approx(float v)
 
 // atomics: lanes never run concurrently here, so plain read-modify-write is exact
 template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = (T)(o + v); return o; }
+template <class T> static inline T atomicSub(T* p, T v) { const T o = *p; *p = (T)(o - v); return o; }
 template <class T> static inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicCAS(T* p, T expect, T v) { const T o = *p; if (o == expect) *p = v; return o; }

@@ -54,7 +54,7 @@ def test_gpu_parity_suite_on_emulated_kernels():
 
 
 VARIANTS = ["fused_geometry", "dirty_blocks,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
-            "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic"]
+            "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic", "near_clip"]
 
 
 def test_pipeline_variants_give_the_same_frames():
@@ -159,7 +159,7 @@ def test_scene_driver_under_address_and_ub_sanitizers():
     exe = build_emu.build_sanitized()
     env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     runs = [(v, subprocess.Popen([exe], env=dict(env, SR_VARIANT=v), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-            for v in ("", "cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic,sparse_tail_force,cluster_cull")]
+            for v in ("", "cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic,sparse_tail_force,cluster_cull", "near_clip")]
     for v, proc in runs:
         out, _ = proc.communicate(timeout=1200)
         assert proc.returncode == 0 and "ok: 32 draws" in out and "runtime error" not in out and "AddressSanitizer" not in out, f"variant '{v}':\n{out[-3000:]}"
@@ -176,7 +176,7 @@ def test_differential_fuzzing_against_the_oracle():
     runs = [(v, subprocess.Popen([sys.executable, script, str(first), "24"], env=dict(os.environ, SR_VARIANT=v), stdout=subprocess.PIPE,
                                  stderr=subprocess.STDOUT, text=True))
             for v, first in (("", 0), ("exact_shading", 100), ("cluster_cull_verify,sparse_tail_force,dirty_blocks,exact_shading", 2300), ("anisotropic", 300),
-                             ("near_clip,dirty_blocks", 3400))]
+                             ("near_clip,dirty_blocks", 3400), ("near_clip", 3500))]
     for v, proc in runs:
         out, _ = proc.communicate(timeout=1500)
         assert proc.returncode == 0 and "ok: seeds" in out, f"variant '{v}':\n{out[-3000:]}"

@@ -102,6 +102,41 @@ def test_near_plane_crossing_is_dropped_and_counted(sr, oracle, device):
         assert got["stats"]["triangles_unprojectable"] == 2 and got["stats"]["triangles_clipped"] == 0
 
 
+@pytest.mark.parametrize("samples", [1, 4])
+def test_fragments_exactly_on_the_far_plane(sr, oracle, device, samples):
+    """Depth test LESS against the cleared 1.0 (src/main.cpp:602-610, :921): a fragment whose depth comes out as exactly
+    1.0 is not drawn.  Triangles lying in the far plane, large and small (tile lists and the direct path), with identity
+    matrices so that every vertex has depth 1.0f exactly: the interpolated depth is 1.0 at some samples and one ulp
+    below at others (the weights sum to one only to an ulp) -- which is which must agree with the oracle, sample
+    for sample."""
+    W, H = 96, 64
+    eye = np.eye(4, dtype=np.float32)
+    ubo = sr.scene.make_ubo(eye, eye, eye, (0.0, 0.0, 0.0))
+    rng = np.random.default_rng(17)
+    tris = [np.array([[-0.93, -0.81, 1.0], [0.87, -0.77, 1.0], [0.05, 0.9, 1.0]])]                       # most of the frame
+    for _ in range(300):                                                                                # and a cloud of a-few-pixel triangles
+        c = rng.uniform(-0.9, 0.9, size=2)
+        d = rng.uniform(-0.06, 0.06, size=(3, 2))
+        t = np.concatenate([c + d, np.ones((3, 1))], axis=1)
+        if (t[1, 0] - t[0, 0]) * (t[2, 1] - t[0, 1]) - (t[2, 0] - t[0, 0]) * (t[1, 1] - t[0, 1]) < 0:   # counter-clockwise on the y-up image
+            t = t[::-1]
+        tris.append(t)
+    verts = np.zeros((3 * len(tris), 8), np.float32)
+    verts[:, :3] = np.concatenate(tris)
+    verts[:, 5] = 1.0
+    verts[:, 6:8] = verts[:, :2]
+    idx = np.arange(3 * len(tris), dtype=np.uint32)
+    images = sr.scene.material_textures(16)
+    got = util.gpu_render(sr, device, verts, idx, images, ubo, W, H, samples)[0]
+    ref = oracle.draw(ubo, verts, idx, images, W, H, samples)
+    util.assert_visibility_equal(got, ref)
+    drawn = ref["tri"] != sr.NO_TRIANGLE
+    assert drawn.any() and not drawn.all() and (ref["depth"][drawn] < 1.0).all()
+    # the case is really there: inside the big triangle some samples are drawn (one ulp below 1.0) and some are not (exactly 1.0)
+    inside = ref["tri"][20:40, 40:56]
+    assert (inside != sr.NO_TRIANGLE).any() and (inside == sr.NO_TRIANGLE).any()
+
+
 def test_empty_mesh_and_offscreen_mesh(sr, oracle, device):
     images = sr.scene.material_textures(16)
     ubo = sr.scene.default_camera_ubo(128, 96)

@@ -7,7 +7,7 @@
 cd /root/repo || exit 1
 VARIANTS=("$@")
 if [ ${#VARIANTS[@]} -eq 0 ]; then
-    VARIANTS=("default" "fused_geometry" "cluster_cull" "dirty_blocks" "cluster_cull,dirty_blocks" "cluster_cull,sparse_tail,dirty_blocks" "cluster_cull,sparse_tail,dirty_blocks,exact_shading" "cluster_cull,sparse_tail,dirty_blocks,near_clip")
+    VARIANTS=("default" "fused_geometry" "cluster_cull" "dirty_blocks" "cluster_cull,dirty_blocks" "cluster_cull,sparse_tail,dirty_blocks" "cluster_cull,sparse_tail,dirty_blocks,exact_shading" "cluster_cull,sparse_tail,dirty_blocks,near_clip" "near_clip")
 fi
 python -c "import __graft_entry__ as g; g.build()" || exit 1
 for v in "${VARIANTS[@]}"; do

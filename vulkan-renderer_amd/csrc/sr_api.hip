@@ -68,7 +68,7 @@ enum : unsigned {
     kVariantRaster512 = 1u << 8,       // "raster_512": the 4-sample tile kernel runs 512 work-items per 32x32 tile; at 1024 it is capped at
                                        //               128 registers and spills 500 bytes per work-item
     kVariantNearClip = 1u << 9,        // "near_clip": triangles with a vertex that cannot be projected are clipped against the near plane
-                                       //              (sr_device.h) instead of dropped (implies fused_geometry, exact_shading)
+                                       //              (sr_device.h) instead of dropped (implies exact_shading)
     kVariantClusterVerify = 1u << 6,   // "cluster_cull_verify": evaluate the cluster test but skip nothing; count what skipped clusters
                                        //                        would have drawn into sr_draw_stats.cull_violations (for tests)
 };
@@ -87,7 +87,7 @@ unsigned parse_variants(const char* text)
         if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "exact_shading") v |= kVariantExactShading;
         if (name == "raster_512") v |= kVariantRaster512;
-        if (name == "near_clip") v |= kVariantNearClip | kVariantFusedGeometry | kVariantExactShading;
+        if (name == "near_clip") v |= kVariantNearClip | kVariantExactShading;
         if (name == "anisotropic") v |= kVariantAnisotropic | kVariantExactShading | kVariantDirtyBlocks | kVariantFusedGeometry;
         if (name == "cluster_cull") v |= kVariantClusterCull | kVariantFusedGeometry;
         if (name == "cluster_cull_verify") v |= kVariantClusterVerify | kVariantClusterCull | kVariantFusedGeometry;
@@ -331,7 +331,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
     SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * setup_block_records() * sizeof(BinRecord)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
-    const bool near_clip = (dev->variants & kVariantNearClip) && m->d_pos4;
+    const bool near_clip = (dev->variants & kVariantNearClip) != 0;
     if (near_clip) SR_HIP(dev->clip.ensure(16 + (size_t)dev->clip_capacity * (sizeof(uint2) + kClipMaxPieces * sizeof(ClipRecord))));
     const bool culling = (dev->variants & kVariantClusterCull) && m->d_clusters && m->d_pos4 && tg->cull_views.size() == n_views;
     const size_t view_bytes = (size_t)n_views * (sizeof(ViewXform) + (culling ? sizeof(ViewCull) : 0));   // [transforms][cull constants]
@@ -422,7 +422,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
             cull.violations = (dev->variants & kVariantClusterVerify) ? dev->d_cull_violations : nullptr;
         }
         ClipList clip{nullptr, nullptr, 0, nullptr, nullptr};
-        if (near_clip && fused) {
+        if (near_clip) {
             clip.state = (uint32_t*)dev->clip.ptr;
             clip.entries = (uint2*)((char*)dev->clip.ptr + 16);
             clip.records = (ClipRecord*)((char*)dev->clip.ptr + 16 + (size_t)dev->clip_capacity * sizeof(uint2));
@@ -430,12 +430,13 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
             clip.count = b.counters + 7;   // zeroed with the other counters at the start of the pass
             SR_HIP(hipMemsetAsync(clip.state, 0, 16, st));
         }
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse, cull, clip);
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse, cull,
+                     fused ? clip : ClipList{nullptr, nullptr, 0, nullptr, nullptr});
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
         // (before the scan / sparse-tail kernel, which reports the number of dropped triangles to the host)
-        if (clip.entries) launch_near_clip(st, m->d_idx, m->n_tris, m->d_pos4, d_views, g, clip, b, tg->d_vis, v0, dirty, pass_counters);
+        if (clip.entries) launch_near_clip(st, m->d_idx, m->n_tris, fused ? m->d_pos4 : nullptr, m->px, m->py, m->pz, sp, nv, d_views, g, clip, b, tg->d_vis, v0, dirty, pass_counters);
         if (sparse) {   // one kernel resolves whatever set-up left pending; its time is reported as the raster stage
             if (ev) { SR_HIP(hipEventRecord(ev[5], st)); SR_HIP(hipEventRecord(ev[6], st)); }
             launch_sparse_tail(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty, pass_counters);
@@ -470,7 +471,7 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
     if (!tg->check_pending) return SR_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
         uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0, clipped = 0;
-        const bool near_clip = (dev->variants & kVariantNearClip) && tg->mesh && tg->mesh->d_pos4;
+        const bool near_clip = (dev->variants & kVariantNearClip) != 0;
         for (uint32_t p = 0; p < tg->passes; ++p) {
             const uint32_t* c = tg->h_counters + (size_t)p * kCountersPerPass;
             worst = std::max<uint64_t>(worst, c[0]); total += c[0]; unproj += c[2]; binned += c[3]; micro += c[4];

@@ -179,13 +179,14 @@ __device__ inline void pixel_span(int32_t lo, int32_t hi, int& p0, int& p1)
     }
 }
 
-// depth key of a covered sample, or false if the fragment falls outside the clip volume in z
+// depth key of a covered sample, or false if the fragment falls outside the clip volume in z -- or lies exactly on the
+// far plane: the depth test is LESS against a buffer cleared to 1.0 (src/main.cpp:602-610, :921), so z = 1.0 never passes
 __device__ inline bool depth_key(const TriSetup& t, int64_t Ea, int64_t Eb, int64_t Ec, uint32_t tri, uint64_t& key)
 {
     const float l0 = (float)Ea * t.rA, l2 = (float)Eb * t.rA, l1 = (float)Ec * t.rA;
     float z = fmaf(l2, t.z2, fmaf(l1, t.z1, l0 * t.z0));
     z = z + 0.0f;
-    if (!(z >= 0.0f && z <= 1.0f)) return false;
+    if (!(z >= 0.0f && z < 1.0f)) return false;
     key = ((uint64_t)__float_as_uint(z) << 32) | (uint64_t)tri;
     return true;
 }
@@ -319,7 +320,8 @@ __device__ inline bool cluster_is_invisible(const ClusterRec& cl, const ViewCull
 // Near-plane clipping (pipeline variant "near_clip").  By default a triangle with one or two vertices that cannot
 // be projected (w <= 0, or outside the guard band) is dropped and counted.  The fixed-function clipper of the
 // reference's pipeline keeps the part of such a triangle inside 0 <= z_c <= w_c (src/main.cpp:559-600 leaves depth
-// clipping on); with the variant on, the fused set-up kernel lists these triangles and two small kernels draw them:
+// clipping on); with the variant on, these triangles are listed (by the fused set-up kernel, or by clip_scan_kernel
+// after the plain one) and two small kernels draw them:
 //   * near_clip_kernel clips each of them in clip space against the near plane and four side planes inside the guard
 //     band (near_clip_polygon below) and writes the convex polygon that is left as up to kClipMaxPieces records of
 //     window-space vertices (a fan);

@@ -199,7 +199,7 @@ __device__ inline void micro_resolve(const MicroEdges& e, uint32_t cov, int x0, 
             const float l0 = (float)Ea * rA, l2 = (float)Eb * rA, l1 = (float)Ec * rA;
             float z = fmaf(l2, z2, fmaf(l1, z1, l0 * z0));
             z = z + 0.0f;
-            if (z >= 0.0f && z <= 1.0f)
+            if (z >= 0.0f && z < 1.0f)
                 atomicMin(&vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S + s], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
         }
         if (++i == npx) { i = 0; ++j; }
@@ -519,7 +519,7 @@ __device__ inline void raster_pixel32(const TriSetup& ts, uint32_t tri, int x, i
         const float l0 = (float)Ea * ts.rA, l2 = (float)Eb * ts.rA, l1 = (float)Ec * ts.rA;
         float z = fmaf(l2, ts.z2, fmaf(l1, ts.z1, l0 * ts.z0));
         z = z + 0.0f;
-        if (!(z >= 0.0f && z <= 1.0f)) continue;
+        if (!(z >= 0.0f && z < 1.0f)) continue;
         atomicMin(cell + s, ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
     }
 }
@@ -738,7 +738,27 @@ __global__ __launch_bounds__(256) void sparse_tail_kernel(const uint32_t* __rest
 // near-plane clipping (pipeline variant, see sr_device.h): one work-item per listed triangle cuts it
 // and writes a record of window-space vertices for every piece ...
 // =================================================================================================
+// Without the fused set-up kernel nothing lists the triangles: the plain set-up kernel only counts them.  When it counted
+// any, this kernel goes over the triangles of the pass once more, finds those with one or two unprojectable vertices in
+// the vertex kernel's planes, lists them and takes them off the count again (a full list leaves them on it).
+__global__ __launch_bounds__(256) void clip_scan_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, uint32_t n_views, ScreenPlanes sp, ClipList clip,
+                                                        uint32_t* __restrict__ counters)
+{
+    if (counters[2] == 0u) return;   // the same for every work-item: the usual frame ends here
+    const uint64_t total = (uint64_t)n_tris * n_views;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x; e < total; e += (uint64_t)gridDim.x * 256u) {
+        const uint32_t view = (uint32_t)(e / n_tris), tri = (uint32_t)(e % n_tris);
+        const int2* xy = sp.xy + (size_t)view * sp.n_verts;
+        const int bad = (xy[idx[3 * (size_t)tri]].x == kBadVertexX) + (xy[idx[3 * (size_t)tri + 1]].x == kBadVertexX) + (xy[idx[3 * (size_t)tri + 2]].x == kBadVertexX);
+        if (bad == 0 || bad == 3) continue;
+        const uint32_t slot = atomicAdd(clip.count, 1u);
+        if (slot < clip.capacity) { clip.entries[slot] = make_uint2(view, tri); atomicSub(&counters[2], 1u); }
+    }
+}
+
+// pos4: packed positions (fused set-up), or null: the three position planes px, py, pz
 __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, const float4* __restrict__ pos4,
+                                                        const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                         const ViewXform* __restrict__ views, FrameGeom g, ClipList clip, uint32_t* __restrict__ counters)
 {
     const uint32_t n = min(*clip.count, clip.capacity);
@@ -750,7 +770,8 @@ __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restri
         ScreenVertex sv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float4 q = pos4[idx[3 * (size_t)tri + k]];
+            const uint32_t i = idx[3 * (size_t)tri + k];
+            const float4 q = pos4 ? pos4[i] : make_float4(px[i], py[i], pz[i], 1.0f);
             sv[k] = project_vertex_short(views[view], q.x, q.y, q.z, g.W, g.H, c[k]);
         }
         ScreenVertex poly[kClipMaxVertices];
@@ -1394,11 +1415,13 @@ void launch_sparse_tail(hipStream_t st, const uint32_t* idx, uint32_t n_tris, co
     else sparse_tail_kernel<4><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
 }
 
-void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* pos4, const ViewXform* views, const FrameGeom& g,
+void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* pos4, const float* px, const float* py, const float* pz,
+                      const ScreenPlanes& sp, uint32_t n_views, const ViewXform* views, const FrameGeom& g,
                       const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0, const DirtyMap& dirty, uint32_t* host_counters)
 {
+    if (!pos4 && n_tris && n_views) clip_scan_kernel<<<1024, 256, 0, st>>>(idx, n_tris, n_views, sp, clip, b.counters);
     // the list is short in any ordinary frame: a few blocks cut it, a few hundred waves share the pieces
-    near_clip_kernel<<<64, 256, 0, st>>>(idx, n_tris, (const float4*)pos4, views, g, clip, b.counters);
+    near_clip_kernel<<<64, 256, 0, st>>>(idx, n_tris, (const float4*)pos4, px, py, pz, views, g, clip, b.counters);
     if (g.samples == 1) clipped_raster_kernel<1><<<512, 256, 0, st>>>(clip, g, (unsigned long long*)vis, view0, dirty, host_counters);
     else clipped_raster_kernel<4><<<512, 256, 0, st>>>(clip, g, (unsigned long long*)vis, view0, dirty, host_counters);
 }

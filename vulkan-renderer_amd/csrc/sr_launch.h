@@ -36,10 +36,13 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
                   bool bin = true /* false: set-up only, the caller resolves the pending triangles with launch_sparse_tail */,
                   const ClusterCull& cull = ClusterCull{nullptr, nullptr, nullptr},
                   const ClipList& clip = ClipList{nullptr, nullptr, 0, nullptr, nullptr} /* with pos4: where triangles that need near-plane clipping are listed */);
-// near-plane clipping of the triangles the fused set-up listed (clip.count must be b.counters + 7, zeroed with the pass;
-// clip.state zeroed by the caller): cuts them, resolves the pieces into the visibility buffer, writes the number of
-// triangles clipped to host_counters[6].  Runs after launch_setup and before launch_scan / launch_sparse_tail.
-void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* pos4, const ViewXform* views, const FrameGeom& g,
+// near-plane clipping of the triangles that need it (clip.count must be b.counters + 7, zeroed with the pass; clip.state
+// zeroed by the caller): cuts them, resolves the pieces into the visibility buffer, writes the number of triangles
+// clipped to host_counters[6].  With pos4 the fused set-up kernel has listed them; without, they are found by a scan of
+// the vertex kernel's planes (sp) and positions are read from px, py, pz.  Runs after launch_setup and before
+// launch_scan / launch_sparse_tail.
+void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* pos4, const float* px, const float* py, const float* pz,
+                      const ScreenPlanes& sp, uint32_t n_views, const ViewXform* views, const FrameGeom& g,
                       const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0, const DirtyMap& dirty, uint32_t* host_counters);
 void launch_count_culled_clusters(hipStream_t st, const ClusterCull& cull, const FrameGeom& g, uint32_t n_clusters, uint32_t n_views, uint64_t* total);
 // resolves every pending triangle of the pass straight into the visibility buffer (in place of bin + scan + fill + raster)
