@@ -53,7 +53,7 @@ def test_gpu_parity_suite_on_emulated_kernels():
     assert "4 skipped" in tails[0], tails[0]
 
 
-VARIANTS = ["fused_geometry", "dirty_blocks,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
+VARIANTS = ["fused_geometry,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
             "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic", "near_clip"]
 
 
