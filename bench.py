@@ -246,7 +246,8 @@ def main():
                        "pipeline_variant": os.environ.get("SR_VARIANT", "") or "default"},
             "frames_per_s": round(frames_per_s, 2),
             "gpixels_shaded_per_s": round(shaded_total * args.steps / elapsed / 1e9, 4),
-            "counters": {"V": V, "T": T, "R": R, "F": F, "P": P, "Pv": Pv, "S": samples, "binned": surv, "direct": stats["triangles_direct"]},
+            "counters": {"V": V, "T": T, "R": R, "F": F, "X": int(Pv * 3 * 1.33), "P": P, "Pv": Pv, "S": samples, "binned": surv, "direct": stats["triangles_direct"],
+                         "note": "X (unique texels over the three maps) is the model Pv*3*1.33, not counted; R = tile references, the direct path adds `direct`"},
             "kernel_ms": {k: round(v, 4) for k, v in kernels.items()},
             "kernel_algorithmic_MB": {k: round(v / 1e6, 1) for k, v in by.items()},
             "frame_algorithmic_bytes": int(frame_bytes),
