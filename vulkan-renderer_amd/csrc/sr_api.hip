@@ -107,7 +107,7 @@ struct sr_device_t {
     float* d_thresh = nullptr;   // 255 (+1 pad)
     // scratch reused by every draw on this device (in-order on `stream`)
     DeviceBuffer screen, tile_count, tile_offset, survivors, survivor_count, refs, views, counters;
-    DeviceBuffer clip;           // kVariantNearClip: [state: 4 words][entries: capacity x 8 bytes][records: kClipMaxPieces x capacity x 48 bytes]
+    DeviceBuffer clip;           // kVariantNearClip: [state: 4 words][entries: capacity x 8 bytes]
     uint32_t clip_capacity = 65536;   // triangles per pass that can be clipped; more are dropped and counted
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
@@ -332,7 +332,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * setup_block_records() * sizeof(BinRecord)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
     const bool near_clip = (dev->variants & kVariantNearClip) != 0;
-    if (near_clip) SR_HIP(dev->clip.ensure(16 + (size_t)dev->clip_capacity * (sizeof(uint2) + kClipMaxPieces * sizeof(ClipRecord))));
+    if (near_clip) SR_HIP(dev->clip.ensure(16 + (size_t)dev->clip_capacity * sizeof(uint2)));
     const bool culling = (dev->variants & kVariantClusterCull) && m->d_clusters && m->d_pos4 && tg->cull_views.size() == n_views;
     const size_t view_bytes = (size_t)n_views * (sizeof(ViewXform) + (culling ? sizeof(ViewCull) : 0));   // [transforms][cull constants]
     SR_HIP(dev->views.ensure(view_bytes));
@@ -421,17 +421,16 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
             cull.views = (const ViewCull*)((const char*)dev->views.ptr + (size_t)n_views * sizeof(ViewXform)) + v0;
             cull.violations = (dev->variants & kVariantClusterVerify) ? dev->d_cull_violations : nullptr;
         }
-        ClipList clip{nullptr, nullptr, 0, nullptr, nullptr};
+        ClipList clip{nullptr, nullptr, 0, nullptr};
         if (near_clip) {
             clip.state = (uint32_t*)dev->clip.ptr;
             clip.entries = (uint2*)((char*)dev->clip.ptr + 16);
-            clip.records = (ClipRecord*)((char*)dev->clip.ptr + 16 + (size_t)dev->clip_capacity * sizeof(uint2));
             clip.capacity = dev->clip_capacity;
             clip.count = b.counters + 7;   // zeroed with the other counters at the start of the pass
             SR_HIP(hipMemsetAsync(clip.state, 0, 16, st));
         }
         launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse, cull,
-                     fused ? clip : ClipList{nullptr, nullptr, 0, nullptr, nullptr});
+                     fused ? clip : ClipList{nullptr, nullptr, 0, nullptr});
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;

@@ -321,25 +321,17 @@ __device__ inline bool cluster_is_invisible(const ClusterRec& cl, const ViewCull
 // be projected (w <= 0, or outside the guard band) is dropped and counted.  The fixed-function clipper of the
 // reference's pipeline keeps the part of such a triangle inside 0 <= z_c <= w_c (src/main.cpp:559-600 leaves depth
 // clipping on); with the variant on, these triangles are listed (by the fused set-up kernel, or by clip_scan_kernel
-// after the plain one) and two small kernels draw them:
-//   * near_clip_kernel clips each of them in clip space against the near plane and four side planes inside the guard
-//     band (near_clip_polygon below) and writes the convex polygon that is left as up to kClipMaxPieces records of
-//     window-space vertices (a fan);
-//   * clipped_raster_kernel resolves the records into the visibility buffer under the id of the triangle they came
-//     from, with the edge functions, depth expression and 64-bit min of every other path.
+// after the plain one) and near_clip_kernel clips each of them in clip space against the near plane and four side
+// planes inside the guard band (near_clip_polygon below) and resolves the convex polygon that is left, as a fan, into
+// the visibility buffer under the id of the triangle it came from -- with the edge functions, depth expression and
+// 64-bit min of every other path.
 // The shading pass recognises such a triangle by its unprojectable vertex and interpolates from clip-space
 // coordinates (shade_pixel).
-struct ClipRecord {            // 48 bytes: one piece of a clipped triangle
-    int32_t X[3], Y[3];        // window coordinates, 1/256 pixel
-    float z[3];
-    uint32_t tri, view, pad;
-};
 struct ClipList {
     uint2* entries;            // (view inside the pass, triangle); null: variant off
     uint32_t* count;           // entries appended by set-up (may exceed capacity: the excess is counted as dropped)
     uint32_t capacity;
-    ClipRecord* records;       // [kClipMaxPieces * capacity]
-    uint32_t* state;           // [0] records written, [1] triangles clipped
+    uint32_t* state;           // [1] triangles clipped, [2] workgroups of near_clip_kernel that have finished (zeroed by the caller)
 };
 
 // window-space record of a clip-space position produced by the clipper: the divide, viewport transform, guard band
@@ -396,7 +388,6 @@ __device__ inline ScreenVertex project_vertex_short(const ViewXform& vx, float p
 // out: up to kClipMaxVertices window-space vertices of a convex polygon, to be drawn as a fan.  Returns their number
 // (0: nothing to draw), or -1 when a vertex that is left cannot be projected (a degenerate projection): dropped and counted.
 constexpr int kClipMaxVertices = 8;     // 3 + one per plane
-constexpr int kClipMaxPieces = kClipMaxVertices - 2;
 struct ClipVertex { float c[4]; ScreenVertex sv; bool original; };   // original: a projectable vertex of the triangle, sv valid
 
 __device__ inline float clip_plane_distance(int plane, const float* c, float kx, float ky)

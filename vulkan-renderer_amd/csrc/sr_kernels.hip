@@ -735,8 +735,7 @@ __global__ __launch_bounds__(256) void sparse_tail_kernel(const uint32_t* __rest
 }
 
 // =================================================================================================
-// near-plane clipping (pipeline variant, see sr_device.h): one work-item per listed triangle cuts it
-// and writes a record of window-space vertices for every piece ...
+// near-plane clipping (pipeline variant, see sr_device.h)
 // =================================================================================================
 // Without the fused set-up kernel nothing lists the triangles: the plain set-up kernel only counts them.  When it counted
 // any, this kernel goes over the triangles of the pass once more, finds those with one or two unprojectable vertices in
@@ -756,15 +755,27 @@ __global__ __launch_bounds__(256) void clip_scan_kernel(const uint32_t* __restri
     }
 }
 
-// pos4: packed positions (fused set-up), or null: the three position planes px, py, pz
+// One kernel cuts the listed triangles and resolves the pieces into the visibility buffer in HBM, 8x8 pixels per step.
+// A work item is (listed triangle, slab): the rows of 8x8 blocks of a piece's box are dealt out to kClipSlabs waves, so
+// that a piece that fills the frame does not hang on one wave; every lane of a wave computes the same polygon (a few
+// hundred instructions, nothing next to the steps of a large piece).  pos4: packed positions (fused set-up), or null:
+// the three position planes px, py, pz.  The workgroup that finishes last writes the number of triangles clipped
+// to host_counters[6].
+constexpr uint32_t kClipSlabs = 16;
+template <int S>
 __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, const float4* __restrict__ pos4,
                                                         const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                        const ViewXform* __restrict__ views, FrameGeom g, ClipList clip, uint32_t* __restrict__ counters)
+                                                        const ViewXform* __restrict__ views, FrameGeom g, ClipList clip, uint32_t* __restrict__ counters,
+                                                        unsigned long long* __restrict__ vis, uint32_t view0, DirtyMap dirty, uint32_t* __restrict__ host_counters)
 {
     const uint32_t n = min(*clip.count, clip.capacity);
-    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u) {
-        const uint2 entry = clip.entries[e];
-        const uint32_t view = entry.x, tri = entry.y;
+    const uint32_t lane = lane_id();
+    const uint32_t waves_total = gridDim.x * 4u, first = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    uint32_t n_clipped = 0, n_dropped = 0;   // counted by the wave that holds a triangle's slab 0
+    for (uint32_t item = first; item < n * kClipSlabs; item += waves_total) {
+        const uint2 entry = clip.entries[item / kClipSlabs];
+        const uint32_t slab = item % kClipSlabs, view = entry.x, tri = entry.y;
         if (tri >= n_tris) continue;   // (the list only ever holds valid ids; cheap insurance against a fault)
         float c[3][4];
         ScreenVertex sv[3];
@@ -776,61 +787,46 @@ __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restri
         }
         ScreenVertex poly[kClipMaxVertices];
         const int np = near_clip_polygon(c, sv, g.W, g.H, poly);
-        if (np < 0) { atomicAdd(&counters[2], 1u); continue; }   // cannot be clipped against the near plane: dropped and counted
+        if (np < 0) { if (slab == 0u) ++n_dropped; continue; }   // cannot be clipped: dropped and counted
         if (np == 0) continue;
-        atomicAdd(&clip.state[1], 1u);
+        if (slab == 0u) ++n_clipped;
+        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
         for (int k = 2; k < np; ++k) {    // fan around the first polygon vertex
-            ClipRecord r;
-            r.X[0] = poly[0].X; r.Y[0] = poly[0].Y; r.z[0] = poly[0].z;
-            r.X[1] = poly[k - 1].X; r.Y[1] = poly[k - 1].Y; r.z[1] = poly[k - 1].z;
-            r.X[2] = poly[k].X; r.Y[2] = poly[k].Y; r.z[2] = poly[k].z;
-            r.tri = tri; r.view = view; r.pad = 0u;
-            clip.records[atomicAdd(&clip.state[0], 1u)] = r;   // at most kClipMaxPieces per entry: the array holds that many times the capacity
+            ScreenVertex v0 = poly[0], v1 = poly[k - 1], v2 = poly[k];
+            v0.rw = v1.rw = v2.rw = 1.0f;
+            TriSetup ts;
+            if (setup_triangle(v0, v1, v2, ts) != 1) continue;
+            int x0, x1, y0, y1;
+            pixel_span<S>(ts.minX, ts.maxX, x0, x1);
+            pixel_span<S>(ts.minY, ts.maxY, y0, y1);
+            x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+            y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+            const bool narrow = fits_32bit(ts);
+            for (int by = y0 + 8 * (int)slab; by <= y1; by += 8 * (int)kClipSlabs)
+                for (int bx = x0; bx <= x1; bx += 8) {
+                    const int x = bx + lx, y = by + ly;
+                    if (x <= x1 && y <= y1) {
+                        unsigned long long* cell = &vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S];
+                        if (narrow) raster_pixel32<S>(ts, tri, x, y, cell);
+                        else raster_pixel<S>(ts, tri, x, y, cell);
+                    }
+                    // the step's four corner lanes mark the (at most four) blocks of the dirty map under it
+                    if (dirty.flags && (lx == 0 || lx == 7) && (ly == 0 || ly == 7))
+                        mark_dirty(dirty, view0 + view, min(x, x1) - g.rx, min(y, y1) - g.ry);
+                }
         }
     }
-}
-
-// ... and the records are resolved into the visibility buffer in HBM, 8x8 pixels per step; the rows of a record's
-// box are dealt out to kClipSlabs waves, so that a piece that fills the frame does not hang on one wave.
-constexpr uint32_t kClipSlabs = 16;
-template <int S>
-__global__ __launch_bounds__(256) void clipped_raster_kernel(ClipList clip, FrameGeom g, unsigned long long* __restrict__ vis, uint32_t view0, DirtyMap dirty,
-                                                             uint32_t* __restrict__ host_counters)
-{
-    const uint32_t n = min(clip.state[0], (uint32_t)kClipMaxPieces * clip.capacity);
-    if (blockIdx.x == 0u && threadIdx.x == 0u) host_counters[6] = clip.state[1];   // triangles clipped in this pass, for the host
-    const uint32_t lane = lane_id();
-    const uint32_t waves_total = gridDim.x * 4u, first = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
-    for (uint32_t item = first; item < n * kClipSlabs; item += waves_total) {   // every lane of the wave holds the same record
-        const ClipRecord& r = clip.records[item / kClipSlabs];
-        const uint32_t slab = item % kClipSlabs;
-        ScreenVertex v0, v1, v2;
-        v0.X = r.X[0]; v0.Y = r.Y[0]; v0.z = r.z[0]; v0.rw = 1.0f;
-        v1.X = r.X[1]; v1.Y = r.Y[1]; v1.z = r.z[1]; v1.rw = 1.0f;
-        v2.X = r.X[2]; v2.Y = r.Y[2]; v2.z = r.z[2]; v2.rw = 1.0f;
-        const uint32_t tri = r.tri, view = r.view;
-        TriSetup ts;
-        if (setup_triangle(v0, v1, v2, ts) != 1) continue;
-        int x0, x1, y0, y1;
-        pixel_span<S>(ts.minX, ts.maxX, x0, x1);
-        pixel_span<S>(ts.minY, ts.maxY, y0, y1);
-        x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
-        y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
-        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
-        const bool narrow = fits_32bit(ts);
-        for (int by = y0 + 8 * (int)slab; by <= y1; by += 8 * (int)kClipSlabs)
-            for (int bx = x0; bx <= x1; bx += 8) {
-                const int x = bx + lx, y = by + ly;
-                if (x <= x1 && y <= y1) {
-                    unsigned long long* cell = &vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S];
-                    if (narrow) raster_pixel32<S>(ts, tri, x, y, cell);
-                    else raster_pixel<S>(ts, tri, x, y, cell);
-                }
-                // the step's four corner lanes mark the (at most four) blocks of the dirty map under it
-                if (dirty.flags && (lx == 0 || lx == 7) && (ly == 0 || ly == 7))
-                    mark_dirty(dirty, view0 + view, min(x, x1) - g.rx, min(y, y1) - g.ry);
-            }
+    if (lane == 0u) {
+        if (n_dropped) atomicAdd(&counters[2], n_dropped);
+        if (n_clipped) atomicAdd(&clip.state[1], n_clipped);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        __threadfence();
+        if (atomicAdd(&clip.state[2], 1u) == gridDim.x - 1u) {
+            __threadfence();
+            host_counters[6] = atomicAdd(&clip.state[1], 0u);
+        }
     }
 }
 
@@ -1420,10 +1416,9 @@ void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, cons
                       const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0, const DirtyMap& dirty, uint32_t* host_counters)
 {
     if (!pos4 && n_tris && n_views) clip_scan_kernel<<<1024, 256, 0, st>>>(idx, n_tris, n_views, sp, clip, b.counters);
-    // the list is short in any ordinary frame: a few blocks cut it, a few hundred waves share the pieces
-    near_clip_kernel<<<64, 256, 0, st>>>(idx, n_tris, (const float4*)pos4, px, py, pz, views, g, clip, b.counters);
-    if (g.samples == 1) clipped_raster_kernel<1><<<512, 256, 0, st>>>(clip, g, (unsigned long long*)vis, view0, dirty, host_counters);
-    else clipped_raster_kernel<4><<<512, 256, 0, st>>>(clip, g, (unsigned long long*)vis, view0, dirty, host_counters);
+    // the list is short in any ordinary frame; two thousand waves share the pieces of a long one
+    if (g.samples == 1) near_clip_kernel<1><<<512, 256, 0, st>>>(idx, n_tris, (const float4*)pos4, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, view0, dirty, host_counters);
+    else near_clip_kernel<4><<<512, 256, 0, st>>>(idx, n_tris, (const float4*)pos4, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, view0, dirty, host_counters);
 }
 
 void launch_count_culled_clusters(hipStream_t st, const ClusterCull& cull, const FrameGeom& g, uint32_t n_clusters, uint32_t n_views, uint64_t* total)

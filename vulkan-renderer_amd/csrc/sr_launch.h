@@ -35,7 +35,7 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
                   const void* pos4 = nullptr, const ViewXform* views = nullptr, const DirtyMap& dirty = DirtyMap{nullptr, 0, 0},
                   bool bin = true /* false: set-up only, the caller resolves the pending triangles with launch_sparse_tail */,
                   const ClusterCull& cull = ClusterCull{nullptr, nullptr, nullptr},
-                  const ClipList& clip = ClipList{nullptr, nullptr, 0, nullptr, nullptr} /* with pos4: where triangles that need near-plane clipping are listed */);
+                  const ClipList& clip = ClipList{nullptr, nullptr, 0, nullptr} /* with pos4: where triangles that need near-plane clipping are listed */);
 // near-plane clipping of the triangles that need it (clip.count must be b.counters + 7, zeroed with the pass; clip.state
 // zeroed by the caller): cuts them, resolves the pieces into the visibility buffer, writes the number of triangles
 // clipped to host_counters[6].  With pos4 the fused set-up kernel has listed them; without, they are found by a scan of
