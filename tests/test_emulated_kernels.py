@@ -39,33 +39,46 @@ def build_emulation_library():
     build_emu.build()   # once, before child processes race to build it
 
 
+VARIANTS = ["fused_geometry,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
+            "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic", "near_clip"]
+_child_runs = {}
+
+
+def child_runs():
+    """The child processes of the three long tests below, all started together the first time one of the tests asks:
+    they keep the machine's cores busy side by side instead of test after test."""
+    if _child_runs:
+        return _child_runs
+    build_emulation_library()
+    subset = "soup or huge or golden or split or multi_view or errors or trailing or reused or far_plane"
+    full = os.path.join("tests", "test_gpu_zz_full_size.py")
+    # (the 64-view, 8K and 16K configurations of that file run at reduced size in the other suites: at full size they take minutes here)
+    full_size = dict(what=full, select="not config and not largest", SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1")
+    _child_runs["full_size"] = [start_gpu_suite_emulated(**full_size),
+                                start_gpu_suite_emulated(SR_VARIANT="cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading", **full_size)]
+    _child_runs["default"] = [start_gpu_suite_emulated("forward"), start_gpu_suite_emulated("reverse", select=subset), start_gpu_suite_emulated("shuffle", select=subset)]
+    _child_runs["variants"] = [start_gpu_suite_emulated("forward", SR_VARIANT=v) for v in VARIANTS]
+    _child_runs["variants"].append(start_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full or huge or cluster or near_plane",
+                                                            SR_VARIANT="cluster_cull,sparse_tail_force,dirty_blocks,exact_shading,near_clip"))
+    return _child_runs
+
+
 def test_gpu_parity_suite_on_emulated_kernels():
     """Whole gpu-marked suite on the default pipeline, lanes scheduled in ascending order; a second and
     third run of the order-sensitive tests with the lanes of every workgroup in descending and in
     shuffled order between synchronisation points (a missing barrier or an order-dependent reservation
     shows up as a parity failure)."""
-    build_emulation_library()
-    subset = "soup or huge or golden or split or multi_view or errors or trailing or reused"
-    runs = [start_gpu_suite_emulated("forward"), start_gpu_suite_emulated("reverse", select=subset), start_gpu_suite_emulated("shuffle", select=subset)]
-    tails = [finish(r) for r in runs]
+    tails = [finish(r) for r in child_runs()["default"]]
     # the two tests that need a real GPU process and the two cases of the near_clip variant's own test are the only
     # ones allowed to be skipped
     assert "4 skipped" in tails[0], tails[0]
-
-
-VARIANTS = ["fused_geometry,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
-            "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic", "near_clip"]
 
 
 def test_pipeline_variants_give_the_same_frames():
     """The switchable pipeline variants (environment variable SR_VARIANT, see sr_api.hip) must pass the
     same parity suite as the default pipeline; the combination of all of them also with the lanes in
     descending order."""
-    build_emulation_library()
-    runs = [start_gpu_suite_emulated("forward", SR_VARIANT=v) for v in VARIANTS]
-    runs.append(start_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full or huge or cluster or near_plane",
-                                         SR_VARIANT="cluster_cull,sparse_tail_force,dirty_blocks,exact_shading,near_clip"))
-    for r in runs:
+    for r in child_runs()["variants"]:
         finish(r)
 
 
@@ -74,13 +87,7 @@ def test_full_size_frame_on_emulated_kernels():
     minute), with every result of the hardware's approximate reciprocal / rsqrt / exp2 / log2 moved
     by up to one ulp: windows against the oracle plus the whole-frame properties -- on the default
     pipeline and on the combination of all variants."""
-    build_emulation_library()
-    what = os.path.join("tests", "test_gpu_zz_full_size.py")
-    # (the 64-view, 8K and 16K configurations of that file run at reduced size in the suites above: at full size they take minutes here)
-    runs = [start_gpu_suite_emulated(what=what, select="not config and not largest", SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1"),
-            start_gpu_suite_emulated(what=what, select="not config and not largest", SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1",
-                                     SR_VARIANT="cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading")]
-    for r in runs:
+    for r in child_runs()["full_size"]:
         finish(r)
 
 
