@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
-"""Benchmark of the draw path: BASELINE config 3 -- one 3840x2160 frame of a 10 M-triangle UV sphere
-with a 4096^2 mip-mapped albedo map (2048^2 metallic / roughness), default reference camera.
+"""Benchmark of the draw path.
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one sr_draw (clear, vertex, set-up + binning, raster, fragment) of one view per GPU with
-mesh and textures already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank
-per GPU) every rank draws its own camera of the same orbit: the path shards by view with no
-collective on the data path (weak scaling).  Rank 0 prints one JSON line.
+N = 1 (default): BASELINE config 3 -- one 3840x2160 frame of a 10 M-triangle UV sphere with a 4096^2
+mip-mapped albedo map (2048^2 metallic / roughness), the reference's default camera, trilinear samplers
+(the sampling the headline configuration names; the time with the reference's own 16x anisotropic
+sampler is reported beside it).  A step is one sr_draw (clear, vertex, set-up + binning, raster,
+fragment) with mesh and textures already resident in HBM.
+
+N > 1: BASELINE config 5 -- the multi-camera batch of a 50 M-triangle mesh sharded sort-last by view:
+every rank draws its 128 cameras of a 1024-camera orbit at 1920x1080 per step, no collective on the data
+path (weak scaling: N = 8 is the whole batch).  One process per GPU; launched by torch.distributed.run,
+or, when WORLD_SIZE is not set, by this script itself, which starts N child ranks before anything touches
+a GPU.  --mode sortfirst times BASELINE config 4 instead (one 7680x4320 frame split into bands over the
+ranks, bands sent to rank 0 over RCCL).  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
-import math
 import os
+import subprocess
 import sys
 import time
 
@@ -27,17 +35,22 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 WORKLOADS = {
-    # name: (width, height, sphere X, sphere Y, albedo size, other maps size, samples, views per GPU)
-    "c3_4k_10Mtri": (3840, 2160, 2500, 2000, 4096, 2048, 1, 1),          # the headline: BASELINE config 3
-    "small_1080p_124ktri": (1920, 1080, 250, 248, 1024, 512, 1, 1),       # for quick checks only
-    "c1_800x600_msaa4": (800, 600, 88, 88, 2048, 2048, 4, 1),             # the reference's own frame: large triangles, 4 samples
-    "c2_1080p_64views": (1920, 1080, 88, 88, 2048, 2048, 1, 64),          # BASELINE config 2: one draw of 64 cameras
+    # name: (width, height, sphere X, sphere Y, albedo size, other maps size, samples, views per GPU, cameras of the whole orbit (0: per-rank camera))
+    "c3_4k_10Mtri": (3840, 2160, 2500, 2000, 4096, 2048, 1, 1, 0),          # the headline: BASELINE config 3
+    "small_1080p_124ktri": (1920, 1080, 250, 248, 1024, 512, 1, 1, 0),       # for quick checks only
+    "c1_800x600_msaa4": (800, 600, 88, 88, 2048, 2048, 4, 1, 0),             # the reference's own frame: large triangles, 4 samples
+    "c2_1080p_64views": (1920, 1080, 88, 88, 2048, 2048, 1, 64, 0),          # BASELINE config 2: one draw of 64 cameras
+    "c5_50Mtri_views": (1920, 1080, 5000, 5000, 2048, 2048, 1, 128, 1024),   # BASELINE config 5: this GPU's 128 of 1024 cameras, 50 M triangles
+    "c5_small": (480, 270, 300, 300, 256, 128, 1, 8, 64),                    # config 5's code path at a size a CPU rehearsal can run
 }
+STAGES = ("clear", "vertex", "setup", "bin", "scan", "fill", "raster", "fragment")
 
 
 def kernel_bytes(st, n_tiles):
-    """Algorithmic (compulsory) HBM bytes of each kernel for one frame: every array counted once per
-    kernel that must touch it, caches assumed perfect inside a kernel.  st: counters of the draw."""
+    """Algorithmic (compulsory) HBM bytes of each kernel for one step: every array counted once per
+    kernel that must touch it, caches assumed perfect inside a kernel.  st: counters of the draw.
+    The fragment figure is the measurement plan's own: visibility read, indices and three 32-byte vertex
+    records per distinct visible triangle (capped by the vertex count), unique texels, colour written."""
     V, T, P, S = st["vertices"], st["triangles"], st["pixels"], st.get("samples", 1)
     B, R, Fd, F, Pv = st["triangles_binned"], st["tile_refs"], st["triangles_direct"], st["visible_triangles"], st["shaded_pixels"]
     X = Pv * 3 * 1.33                       # unique texels over the three maps (model)
@@ -50,8 +63,42 @@ def kernel_bytes(st, n_tiles):
         "scan": n_tiles * 12,
         "fill": R * 12 + R * 4,                                                # records read, references written
         "raster": R * 4 + R * 12 + min(V, 3 * R) * 12 + (Pv * S - direct_samples) * 8,
-        "fragment": P * S * 8 + F * 12 + min(V, 3 * F) * 48 + X * 4 + P * 4,  # visibility, indices, vertex records + window planes, texels, colour
+        "fragment": P * S * 8 + F * 12 + min(V, 3 * F) * 32 + X * 4 + P * 4,  # visibility, indices, vertex records, texels, colour
     }
+
+
+def frame_bytes_reference_model(st):
+    """The per-frame figure of the measurement plan this benchmark follows: vertex V*28; set-up/bin
+    T*12 + V*16 + R*4; raster R*4 + R*12 + V*16 + P*S*8; fragment P*S*8 + F*108 + X*4 + P*4, with R =
+    surviving (triangle, tile) references (here: tile references + directly resolved triangles)."""
+    V, T, P, S = st["vertices"], st["triangles"], st["pixels"], st.get("samples", 1)
+    R = st["tile_refs"] + st["triangles_direct"]
+    F, Pv = st["visible_triangles"], st["shaded_pixels"]
+    X = Pv * 3 * 1.33
+    return (V * 28) + (T * 12 + V * 16 + R * 4) + (R * 4 + R * 12 + V * 16 + P * S * 8) + (P * S * 8 + F * 108 + X * 4 + P * 4)
+
+
+def kernel_source_digest():
+    """Identifies the kernels a profile was taken on: a digest of the device sources (there is no git on the GPU box)."""
+    h = hashlib.sha256()
+    for f in ("sr_kernels.hip", "sr_device.h", "sr_launch.h", "sr_api.hip"):
+        with open(os.path.join(ROOT, "vulkan-renderer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/profiles_to_repo.py) -- only if they were taken on the kernels this run uses; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if t.get("kernel_source_digest") != kernel_source_digest():
+        return None
+    return t.get(workload, {}).get(kernel)
 
 
 def lavapipe_status():
@@ -71,20 +118,43 @@ def lavapipe_status():
     return f"Vulkan loader {'present' if loader else 'absent'}, lvp ICD {'present' if icds else 'absent'}; the reference application is not buildable here"
 
 
-def frame_bytes_reference_model(st):
-    """The per-frame figure of the measurement plan this benchmark follows: vertex V*28; set-up/bin
-    T*12 + V*16 + R*4; raster R*4 + R*12 + V*16 + P*S*8; fragment P*S*8 + F*108 + X*4 + P*4, with R =
-    surviving (triangle, tile) references (here: tile references + directly resolved triangles)."""
-    V, T, P, S = st["vertices"], st["triangles"], st["pixels"], st.get("samples", 1)
-    R = st["tile_refs"] + st["triangles_direct"]
-    F, Pv = st["visible_triangles"], st["shaded_pixels"]
-    X = Pv * 3 * 1.33
-    return (V * 28) + (T * 12 + V * 16 + R * 4) + (R * 4 + R * 12 + V * 16 + P * S * 8) + (P * S * 8 + F * 108 + X * 4 + P * 4)
+def spawn_ranks(n):
+    """--gpus N without a launcher: start N ranks of this script (fresh processes; this one has not touched a GPU and
+    does not), wait for them, exit with the worst of their exit codes."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    raise SystemExit(max(abs(c) for c in codes))
+
+
+def init_ranks(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+    return rank, local_rank, world
 
 
 def sort_first(args, sr, rank, local_rank, world):
-    """BASELINE config 4: the 10 M-triangle scene at 7680x4320, the frame split into horizontal bands over
-    the ranks (mesh and textures replicated), finished BGRA8 bands gathered on rank 0 over RCCL."""
+    """BASELINE config 4: the 10 M-triangle scene at 7680x4320, the frame split into horizontal bands over the ranks
+    (mesh and textures replicated; cut rows balanced by the coverage of a first frame), every rank's finished BGRA8
+    band sent straight into its rows of rank 0's frame.  Two frame slots: the exchange of a frame overlaps the
+    drawing of the next."""
     import torch
     import torch.distributed as dist
     from softraster import distributed as d
@@ -95,26 +165,45 @@ def sort_first(args, sr, rank, local_rank, world):
     torch.cuda.set_device(local_rank)
     dev = sr.Device(local_rank)
     mesh = sr.create_mesh_from_data(dev, verts, idx)
-    tex = [sr.create_texture(dev, im) if im is not None else None for im in images]
-    bands = d.split_bands(W, H, world)
-    band = bands[rank]
-    out = torch.empty((band[3], band[2], 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
-    tgt = sr.RenderTarget(dev, W, H, samples=1, n_views=1, rect=band)
-    tgt.bind_color(out.data_ptr())
-
-    def step():
-        sr.draw(dev, tgt, mesh, ubo, tex)
-        dev.synchronize()
-        return d.gather_bands(out, bands, rank, dst=0) if world > 1 else out
-
-    for _ in range(max(args.warmup, 1)):
-        step()
-    torch.cuda.synchronize()
+    tex = [sr.create_texture(dev, im, sampler=sr.default_sampler(1.0)) if im is not None else None for im in images]
+    # cost profile: one frame over equal bands, covered pixels per row, summed over the ranks
+    even = d.split_bands(W, H, world)
+    probe = sr.RenderTarget(dev, W, H, samples=1, n_views=1, rect=even[rank])
+    sr.draw(dev, probe, mesh, ubo, tex)
+    rows = torch.zeros(H, dtype=torch.float64, device=f"cuda:{local_rank}")
+    covered = (probe.read_triangle_ids(0)[..., 0] != sr.NO_TRIANGLE).sum(axis=1).astype(np.float64)
+    rows[even[rank][1]:even[rank][1] + even[rank][3]] = torch.from_numpy(covered).to(rows.device)
+    probe.destroy()
     if world > 1:
-        dist.barrier()
+        dist.all_reduce(rows)
+    bands = d.balance_bands(W / 8 + rows.cpu().numpy(), W, world)
+    comp = d.BandCompositor(bands, rank, world, f"cuda:{local_rank}", dst=0, slots=2)
+    targets = []
+    for slot in range(2):
+        t = sr.RenderTarget(dev, W, H, samples=1, n_views=1, rect=bands[rank])
+        t.bind_color(comp.local(slot).data_ptr())
+        targets.append(t)
+
+    def step(i):
+        slot = i % 2
+        comp.wait(slot)                  # the slot's previous exchange is over: it may be drawn into again
+        sr.draw(dev, targets[slot], mesh, ubo, tex)
+        dev.synchronize()                # the band is finished before it is sent
+        comp.exchange(slot)
+
+    def drain():
+        comp.wait(0); comp.wait(1)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(max(args.warmup, 1)):
+        step(i)
+    drain()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    comp.wait(0); comp.wait(1)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -128,12 +217,15 @@ def sort_first(args, sr, rank, local_rank, world):
             "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "c4_8k_sort_first", "width": W, "height": H, "triangles": T, "bands": bands,
-                       "composite": "torch.distributed gather of BGRA8 bands (RCCL)" if world > 1 else "none"},
+                       "composite": "point-to-point sends of BGRA8 bands into rank 0's frame (RCCL), double-buffered" if world > 1 else "none"},
             "frames_per_s": round(args.steps / elapsed, 2)}), flush=True)
+    drain()
     for t_ in tex:
         if t_ is not None:
             t_.destroy()
-    tgt.destroy(); mesh.destroy(); dev.close()
+    for t_ in targets:
+        t_.destroy()
+    mesh.destroy(); dev.close()
     if world > 1:
         dist.destroy_process_group()
 
@@ -143,40 +235,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3_4k_10Mtri", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c3_4k_10Mtri on one GPU, c5_50Mtri_views (sharded by view) on several")
     ap.add_argument("--mode", default="views", choices=["views", "sortfirst"],
-                    help="views: every rank draws its own camera of the workload (weak scaling, no collective); "
-                         "sortfirst: one 7680x4320 frame split into bands over the ranks, bands gathered on rank 0 (strong scaling)")
+                    help="views: every rank draws its own cameras of the workload (weak scaling, no collective); "
+                         "sortfirst: one 7680x4320 frame split into bands over the ranks, bands sent to rank 0 (strong scaling)")
+    ap.add_argument("--max-anisotropy", type=float, default=1.0, help="maxAnisotropy of the samplers of the timed run (1: trilinear; the reference's own sampler has 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+    rank, local_rank, world = init_ranks(args)
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import softraster as sr
     if args.mode == "sortfirst":
         return sort_first(args, sr, rank, local_rank, world)
-    W, H, SX, SY, alb_size, map_size, samples, views = WORKLOADS[args.workload]
+    workload = args.workload or ("c3_4k_10Mtri" if world == 1 else "c5_50Mtri_views")
+    W, H, SX, SY, alb_size, map_size, samples, views, orbit = WORKLOADS[workload]
     verts, idx = sr.scene.uv_sphere(SX, SY)
     images = [sr.scene.albedo_pattern(alb_size), None, sr.scene.gray_map(map_size, map_size, 0, 254), sr.scene.gray_map(map_size, map_size, 72, 255)]
-    # rank r draws view r of a `world`-camera orbit; view 0 is the reference's default camera
-    ubo = sr.scene.default_camera_ubo(W, H, eye=sr.scene.orbit_eye(rank, max(world, 1)) if world > 1 else (2.0, 2.0, 2.0))
-    if views > 1:   # a batch: this rank's share of a world*views-camera orbit
+    if orbit:       # a share of a fixed orbit of cameras: rank r draws cameras r*views .. r*views + views - 1
+        ubo = sr.scene.orbit_ubos(views, W, H, first=(rank * views) % orbit, total=orbit)
+    elif views > 1:  # a batch of this rank's own
         ubo = sr.scene.orbit_ubos(views, W, H, first=rank * views, total=world * views)
+    else:            # rank r draws view r of a `world`-camera orbit; view 0 is the reference's default camera
+        ubo = sr.scene.default_camera_ubo(W, H, eye=sr.scene.orbit_eye(rank, max(world, 1)) if world > 1 else (2.0, 2.0, 2.0))
 
     dev = sr.Device(local_rank)
     mesh = sr.create_mesh_from_data(dev, verts, idx)
-    tex = [sr.create_texture(dev, im) if im is not None else None for im in images]
+    tex = [sr.create_texture(dev, im, sampler=sr.default_sampler(args.max_anisotropy)) if im is not None else None for im in images]
     tgt = sr.RenderTarget(dev, W, H, samples=samples, n_views=views)
 
     def barrier():
@@ -185,16 +276,19 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    def timed(textures, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sr.draw(dev, tgt, mesh, ubo, textures)
+        dev.synchronize()
+        return time.perf_counter() - t0
+
     for _ in range(max(args.warmup, 1)):   # the first draw also sizes the tile reference list
         sr.draw(dev, tgt, mesh, ubo, tex)
     stats = tgt.stats()
     stats["samples"] = samples
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sr.draw(dev, tgt, mesh, ubo, tex)
-    dev.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed = timed(tex, args.steps)
     if world > 1:
         torch.cuda.synchronize()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -203,8 +297,12 @@ def main():
         pv = torch.tensor([float(stats["shaded_pixels"])], dtype=torch.float64, device="cuda")
         dist.all_reduce(pv, op=dist.ReduceOp.SUM)
         shaded_total = float(pv.item())
+        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(every, torch.tensor([own_elapsed], dtype=torch.float64, device="cuda"))
+        per_rank_s = [float(e.item()) for e in every]
     else:
         shaded_total = float(stats["shaded_pixels"])
+        per_rank_s = [elapsed]
 
     # per-kernel durations from HIP events on the library's own stream, same K steps
     dev.profile(True)
@@ -225,39 +323,46 @@ def main():
         tile = 64 if samples == 1 else 32
         n_tiles = ((W + tile - 1) // tile) * ((H + tile - 1) // tile) * views
         by = kernel_bytes(stats, n_tiles)
-        kernels = {k: stage_ms[k + "_ms"] for k in ("clear", "vertex", "setup", "bin", "scan", "fill", "raster", "fragment")}
+        kernels = {k: stage_ms[k + "_ms"] for k in STAGES}
         dom = max(kernels, key=kernels.get)
         achieved = by[dom] / (kernels[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes, if collected
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
-            except Exception:
-                traffic = None
         frame_bytes = frame_bytes_reference_model(stats)
+        metric = {"c3_4k_10Mtri": "Mtris/s, 3840x2160 frame of a 10M-triangle mesh with 4096^2 mip-mapped texture",
+                  "c5_50Mtri_views": "Mtris/s, 1024-camera batch of a 50M-triangle mesh at 1920x1080, sharded by view"}.get(workload, "Mtris/s")
         out = {
-            "metric": "Mtris/s, 3840x2160 frame of a 10M-triangle mesh with 4096^2 mip-mapped texture" if args.workload == "c3_4k_10Mtri" else "Mtris/s",
+            "metric": metric,
             "value": round(mtris, 2), "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "width": W, "height": H, "triangles": T // views, "vertices": V // views, "samples": samples,
+            "config": {"workload": workload, "width": W, "height": H, "triangles": T // views, "vertices": V // views, "samples": samples,
                        "views_per_gpu": views, "sharding": "by view (no collective)" if world > 1 else "single GPU",
-                       "pipeline_variant": os.environ.get("SR_VARIANT", "") or "default"},
+                       "max_anisotropy": args.max_anisotropy},
             "frames_per_s": round(frames_per_s, 2),
             "gpixels_shaded_per_s": round(shaded_total * args.steps / elapsed / 1e9, 4),
+            "per_gpu_Mtris_per_s": [round((T // views) * views * args.steps / s / 1e6, 1) for s in per_rank_s],
             "counters": {"V": V, "T": T, "R": R, "F": F, "X": int(Pv * 3 * 1.33), "P": P, "Pv": Pv, "S": samples, "binned": surv, "direct": stats["triangles_direct"],
+                         "clipped": stats["triangles_clipped"],
                          "note": "X (unique texels over the three maps) is the model Pv*3*1.33, not counted; R = tile references, the direct path adds `direct`"},
             "kernel_ms": {k: round(v, 4) for k, v in kernels.items()},
             "kernel_algorithmic_MB": {k: round(v / 1e6, 1) for k, v in by.items()},
             "frame_algorithmic_bytes": int(frame_bytes),
             "frame_hbm_fraction": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": int(by[dom])},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(workload, dom), "algorithmic_bytes": int(by[dom]),
+                         "kernel_source_digest": kernel_source_digest()},
         }
+        if world == 1 and args.max_anisotropy <= 1.0:
+            # the same frame through the sampler the reference creates (maxAnisotropy 16): a second figure, not the headline
+            tex16 = [sr.create_texture(dev, im, sampler=sr.default_sampler(16.0)) if im is not None else None for im in images]
+            sr.draw(dev, tgt, mesh, ubo, tex16)
+            out["ms_per_step_max_anisotropy_16"] = round(timed(tex16, args.steps) / args.steps * 1e3, 4)
+            for t in tex16:
+                if t is not None:
+                    t.destroy()
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: the other ranks would sit in the final barrier meanwhile
             from oracle import oracle
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            oracle.set_anisotropic(args.max_anisotropy > 1.0)
             chains = [(oracle.build_mip_chain(im), im.shape[1], im.shape[0]) if im is not None else (np.zeros((1, 4), np.uint8), 1, 1) for im in images]
             tc = time.perf_counter()
             oracle.draw(ubo if views == 1 else ubo[0], verts, idx, chains, W, H, samples, threads=threads)

@@ -46,7 +46,9 @@ typedef struct sr_sampler_desc {
     float min_lod;        /* 0 */
     float max_lod;        /* (float)mip_levels; a negative value means "use mip_levels" */
     float mip_lod_bias;   /* 0 */
-    float max_anisotropy; /* 16; recorded, the filter footprint stays isotropic */
+    float max_anisotropy; /* 16 (anisotropyEnable, src/texture.cpp:255-256).  > 1: the footprint the Vulkan specification
+                             describes (N = ceil(min(rho_max/rho_min, max)) trilinear taps along the major axis);
+                             <= 1: isotropic trilinear filtering */
 } sr_sampler_desc;
 
 typedef struct sr_rect { int32_t x, y, width, height; } sr_rect;
@@ -65,18 +67,16 @@ typedef struct sr_draw_stats {
     uint64_t triangles;           /* T: triangles submitted */
     uint64_t triangles_binned;    /* surviving triangles that were not resolved by the set-up kernel itself */
     uint64_t tile_refs;           /* (triangle, tile) references emitted for them; 0 if they were resolved without tile lists */
-    uint64_t triangles_unprojectable; /* dropped: a vertex at w <= 0 or outside the guard band (with the near_clip pipeline
-                                         variant: only those the near-plane clipper could not handle) */
+    uint64_t triangles_unprojectable; /* dropped: triangles with a vertex at w <= 0 or outside the guard band that the near-plane
+                                         clipper could not handle (more than 65536 of them in one pass, or a degenerate projection);
+                                         a frame with a non-zero count is incomplete */
     uint64_t shaded_pixels;       /* Pv: pixels with at least one covered sample */
     uint64_t visible_triangles;   /* F: distinct triangles owning at least one sample */
     uint64_t pixels;              /* P: pixels of the stored rectangle */
     uint64_t triangles_direct;    /* micro-triangles resolved by the set-up kernel itself (they cover >= 1 sample) */
-    uint64_t clusters_culled;     /* (view, 64-triangle cluster) pairs skipped before any per-triangle work; 0 unless the
-                                     cluster_cull pipeline variant is on */
-    uint64_t cull_violations;     /* cluster_cull_verify variant: triangles of would-be-skipped clusters that the per-triangle
-                                     path draws or counts; anything but 0 is a bug */
-    uint64_t triangles_clipped;   /* near_clip variant: triangles with a vertex behind the eye that were cut at the near plane
-                                     and drawn (the fixed-function clipping of the reference's pipeline); 0 otherwise */
+    uint64_t triangles_clipped;   /* triangles with a vertex behind the eye (or outside the guard band) that were cut at the near
+                                     plane and drawn: the fixed-function clipping of the reference's pipeline
+                                     (depthClampEnable = VK_FALSE, src/main.cpp:586) */
 } sr_draw_stats;
 
 /* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */
@@ -96,7 +96,10 @@ SR_API const char* sr_last_error_string(void);
 /* ---- mesh: replaces create_mesh_from_data, src/mesh.hpp:69-72 / src/mesh.cpp:79-87.
  * vertices: n_vertices records of the reference's Vertex (32 bytes: pos f32x3, normal f32x3,
  * uv f32x2; src/mesh.hpp:18-54).  indices: uint32 triangle list (src/main.cpp:561, 947-948).
- * Data is fully uploaded on return, as with the reference's blocking staging copies. */
+ * Data is fully uploaded on return, as with the reference's blocking staging copies.
+ * A mesh (and a texture) may be destroyed at any time after the draws that use it were issued: sr_mesh_destroy and
+ * sr_texture_destroy first complete those draws, as the reference waits for the device to be idle before it
+ * destroys its buffers (src/main.cpp:170, 300-347). */
 SR_API int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices,
                           const uint32_t* indices, uint32_t n_indices, sr_mesh* out);
 SR_API int sr_mesh_destroy(sr_device dev, sr_mesh mesh);

@@ -16,7 +16,7 @@ def pytest_configure(config):
 # Within test_gpu_parity.py the tests of the basic draw paths are run before those of the grow-and-repeat,
 # hash-overflow, pass-splitting, target-reuse and file-loading paths: the suite is run with -x, and a failure in
 # one of the special paths should not hide the results of the basic ones.
-RUN_AFTER_THE_BASIC_PARITY_TESTS = ("test_target_is_reused_across_different_draws", "test_cluster_culling_never_drops_a_drawn_triangle",
+RUN_AFTER_THE_BASIC_PARITY_TESTS = ("test_target_is_reused_across_different_draws", "test_mesh_and_textures_destroyed_before_the_read_back",
                                     "test_model_and_textures_from_files", "test_tile_reference_list_grows_and_the_draw_is_repeated",
                                     "test_more_distinct_tiles_than_a_binning_block_can_hash", "test_view_batch_split_into_passes", "test_near_plane_clipper",
                                     "test_fragments_exactly_on_the_far_plane")
@@ -33,10 +33,8 @@ def pytest_collection_modifyitems(config, items):
 def oracle():
     from oracle import oracle as o
     o.build()
-    # the "anisotropic" pipeline variant is checked against the oracle's anisotropic footprint
-    o.set_anisotropic("anisotropic" in os.environ.get("SR_VARIANT", ""))
-    # and the "near_clip" variant against the oracle's near-plane clipper
-    o.set_near_clip("near_clip" in os.environ.get("SR_VARIANT", ""))
+    o.set_anisotropic(False)   # the session's default sampler is isotropic (see `sr` below); the `anisotropic` fixture switches both
+    o.set_near_clip(True)      # the library clips at the near plane, as the reference's pipeline does
     return o
 
 
@@ -54,7 +52,22 @@ def sr():
         import build_emu
         softraster.LIB_PATH = build_emu.build()
         print(f"\n*** SR_TEST_EMULATED=1: kernels run on the CPU through {softraster.LIB_PATH} ***")
+    # Textures made without an explicit sampler are trilinear (maxAnisotropy 1) in this session: the committed fixtures
+    # and the headline configuration are.  Tests that take the `anisotropic` fixture run a second time with the
+    # reference's own sampler (maxAnisotropy 16) on both sides.
+    softraster.DEFAULT_MAX_ANISOTROPY = 1.0
     return softraster
+
+
+@pytest.fixture(params=[False, True], ids=["trilinear", "aniso16"])
+def anisotropic(request, sr, oracle):
+    """Runs the test once with trilinear samplers and once with the reference's maxAnisotropy = 16
+    (src/texture.cpp:255-256) in the library and in the oracle."""
+    sr.DEFAULT_MAX_ANISOTROPY = 16.0 if request.param else 1.0
+    oracle.set_anisotropic(request.param)
+    yield request.param
+    sr.DEFAULT_MAX_ANISOTROPY = 1.0
+    oracle.set_anisotropic(False)
 
 
 @pytest.fixture(scope="session")

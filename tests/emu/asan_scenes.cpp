@@ -3,7 +3,6 @@
 // catch out-of-range accesses to device allocations; this build adds the workgroup-local arrays
 // (__shared__ becomes static, which AddressSanitizer fences like any global) and the host side of the
 // library.  Results are not checked here (the parity tests do that); the run must simply be clean.
-//   asan_scenes            default pipeline; SR_VARIANT in the environment selects pipeline variants
 #include "../../include/softraster.h"
 
 #include <cmath>
@@ -107,12 +106,12 @@ int main()
         const int rw = f.use_rect ? f.rect.width : f.W, rh = f.use_rect ? f.rect.height : f.H;
         std::vector<uint8_t> color((size_t)rw * rh * 4);
         std::vector<uint64_t> vis((size_t)rw * rh * f.samples);
-        for (int repeat = 0; repeat < 2; ++repeat)   // twice: the second frame of a target takes the reuse paths (dirty map, sparse tail)
+        for (int repeat = 0; repeat < 2; ++repeat)   // twice: the second frame of a target reuses every scratch buffer
             for (Scene& s : scenes) {
                 std::vector<float> ubo(52 * f.views);
                 for (uint32_t v = 0; v < f.views; ++v) look_at_ubo(&ubo[52 * v], f.W, f.H, 2.0f + 0.7f * v, 2.0f - 0.9f * v, 1.0f + v);
                 // the last view of a multi-view frame from inside the scene: triangles behind and across the eye plane
-                // (dropped and counted, or clipped with the near_clip variant)
+                // (cut at the near plane by the clipper)
                 if (f.views > 1) look_at_ubo(&ubo[52 * (f.views - 1)], f.W, f.H, 0.3f, 0.2f, 0.1f);
                 CHECK(sr_draw(dev, tgt, s.mesh, ubo.data(), f.views, 208, tex));
                 for (uint32_t v = 0; v < f.views; ++v) {
@@ -121,7 +120,6 @@ int main()
                 }
                 sr_draw_stats st;
                 CHECK(sr_draw_get_stats(dev, tgt, &st));
-                if (st.cull_violations) { std::printf("cluster culling violation\n"); return 1; }
                 ++draws;
             }
         CHECK(sr_target_destroy(dev, tgt));

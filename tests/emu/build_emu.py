@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "vulkan-renderer_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "libsoftraster_emu.so")
 SOURCES = ("sr_kernels.hip", "sr_api.hip")
-HEADERS = ("sr_device.h", "sr_launch.h", "sr_setup_body.inc", "sr_assets.h", "sr_assets.cpp", "sr_jpeg.cpp")
+HEADERS = ("sr_device.h", "sr_launch.h", "sr_assets.h", "sr_assets.cpp", "sr_jpeg.cpp")
 
 _LAUNCH = re.compile(r"([A-Za-z_]\w*(?:<[^<>;()]*>)?)\s*<<<(.*?)>>>\s*\(")
 

@@ -4,7 +4,7 @@ matrices and cameras, random frame sizes, sample counts, stored rectangles and v
 must be bit-exact, colour within 1 LSB on 99.9 % of the pixels (on frames with enough covered pixels for
 the percentage to mean something).
 
-    python tests/emu/fuzz_parity.py [first_seed [count]]        SR_VARIANT selects pipeline variants
+    python tests/emu/fuzz_parity.py [first_seed [count]]        SR_FUZZ_ANISOTROPIC=1: samplers with maxAnisotropy 16 on both sides
 """
 import os
 import sys
@@ -53,81 +53,84 @@ def random_scene(rng):
     return verts, idx
 
 
+def scene_of_seed(seed, sr):
+    """Everything one fuzz case consists of, as a dict; deterministic in the seed."""
+    import test_gpu_parity as T
+    rng = np.random.default_rng(seed)
+    verts, idx = random_scene(rng)
+    W, H = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+    if seed % 16 == 5:   # now and then a frame of many tiles
+        W, H = int(rng.integers(600, 1500)), int(rng.integers(400, 900))
+    samples = int(rng.choice([1, 4]))
+    n_views = int(rng.integers(1, 4))
+    rect = None
+    if rng.integers(0, 3) == 0:
+        x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
+        rect = (x, y, int(rng.integers(1, W - x + 1)), int(rng.integers(1, H - y + 1)))
+    ubos = np.stack([T._random_view(rng, W, H, sr) for _ in range(n_views)])
+    if rng.integers(0, 4) == 0:   # a camera inside the cloud: vertices behind the eye
+        ubos[0] = sr.scene.default_camera_ubo(W, H, eye=(0.1, 0.05, 0.02))
+    size = [int(rng.choice([1, 2, 3, 8, 17, 64])) for _ in range(2)]
+    images = [sr.scene.noise_rgba(size[0], size[1], seed), sr.scene.constant_rgba(1, 1, (128, 128, 255, 255)),
+              sr.scene.noise_rgba(size[1], size[0], seed + 1), sr.scene.noise_rgba(size[0], size[0], seed + 2)]
+    return {"verts": verts, "idx": idx, "W": W, "H": H, "samples": samples, "rect": rect, "ubos": ubos, "images": images}
+
+
+def check_seed(seed, sr, oracle, dev, util, vertex_stage_too=False):
+    """Draws the case of `seed` through the C ABI and with the oracle: visibility and the clipped / given-up counts must
+    be equal, colour must meet the bar on every frame with enough covered pixels for a percentage to mean something.
+    Returns (lowest colour fraction over such frames, triangles clipped, triangles given up)."""
+    sc = scene_of_seed(seed, sr)
+    verts, idx, W, H, samples, rect, ubos, images = (sc[k] for k in ("verts", "idx", "W", "H", "samples", "rect", "ubos", "images"))
+    if vertex_stage_too:   # the vertex stage on its own: clip coordinates and window-space records, bit for bit
+        mesh = sr.create_mesh_from_data(dev, verts, idx)
+        clip, screen = mesh.vertex_stage(ubos[0], W, H)
+        rclip, rscreen = oracle.vertex_stage(ubos[0], verts, W, H)
+        mesh.destroy()
+        assert np.array_equal(clip.view(np.uint32), rclip.view(np.uint32)), f"seed {seed}: clip coordinates differ"
+        for field in ("X", "Y", "z", "rw"):
+            assert np.array_equal(screen[field].view(np.uint32), rscreen[field].view(np.uint32)), f"seed {seed}: window-space {field} differs"
+    got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples, rect=rect)
+    ref_dropped = ref_clipped = 0
+    lowest = 1.0
+    for v in range(len(ubos)):
+        ref = oracle.draw(ubos[v], verts, idx, images, W, H, samples, rect=rect)
+        what = f"seed {seed} view {v}: {idx.size // 3} triangles, {W}x{H}x{samples}, rect {rect}"
+        assert np.array_equal(got[v]["tri"], ref["tri"]), what + f": triangle ids differ at {int((got[v]['tri'] != ref['tri']).sum())} samples"
+        assert np.array_equal(got[v]["depth"].view(np.uint32), ref["depth"].view(np.uint32)), what + ": depth bits differ"
+        ref_dropped += ref["stats"]["tris_clip_culled"]; ref_clipped += ref["stats"]["tris_clipped"]
+        covered = int((ref["tri"] != 0xFFFFFFFF).any(axis=-1).sum())
+        frac, worst = util.color_match_fraction(got[v]["bgra"], ref["bgra"], 1)
+        if covered >= 2000:
+            lowest = min(lowest, frac)
+            assert frac >= 0.999, what + f": colour within 1 LSB on {frac:.5f} (worst {worst})"
+    st = got[0]["stats"]
+    # dropped are only the triangles the near-plane clipper gives up on
+    assert st["triangles_unprojectable"] == ref_dropped and st["triangles_clipped"] == ref_clipped, f"seed {seed}: dropped / clipped counts {st} vs {ref_dropped}, {ref_clipped}"
+    return lowest, ref_clipped, ref_dropped
+
+
 def main():
     import build_emu
     import softraster as sr
     import util
     from oracle import oracle
-    import test_gpu_parity as T
     sr.LIB_PATH = build_emu.build()
-    oracle.set_anisotropic("anisotropic" in os.environ.get("SR_VARIANT", ""))
-    near_clip = "near_clip" in os.environ.get("SR_VARIANT", "")
-    oracle.set_near_clip(near_clip)
+    aniso = os.environ.get("SR_FUZZ_ANISOTROPIC") == "1"
+    sr.DEFAULT_MAX_ANISOTROPY = 16.0 if aniso else 1.0
+    oracle.set_anisotropic(aniso)
+    oracle.set_near_clip(True)
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     dev = sr.Device(0)
     worst_frac = 1.0
     total_clipped = total_dropped = 0
     for seed in range(first, first + count):
-        rng = np.random.default_rng(seed)
-        verts, idx = random_scene(rng)
-        W, H = int(rng.integers(1, 300)), int(rng.integers(1, 200))
-        if seed % 16 == 5:   # now and then a frame of many tiles
-            W, H = int(rng.integers(600, 1500)), int(rng.integers(400, 900))
-        samples = int(rng.choice([1, 4]))
-        n_views = int(rng.integers(1, 4))
-        rect = None
-        if rng.integers(0, 3) == 0:
-            x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
-            rect = (x, y, int(rng.integers(1, W - x + 1)), int(rng.integers(1, H - y + 1)))
-        ubos = np.stack([T._random_view(rng, W, H, sr) for _ in range(n_views)])
-        if rng.integers(0, 4) == 0:   # a camera inside the cloud: vertices behind the eye
-            ubos[0] = sr.scene.default_camera_ubo(W, H, eye=(0.1, 0.05, 0.02))
-        size = [int(rng.choice([1, 2, 3, 8, 17, 64])) for _ in range(2)]
-        images = [sr.scene.noise_rgba(size[0], size[1], seed), sr.scene.constant_rgba(1, 1, (128, 128, 255, 255)),
-                  sr.scene.noise_rgba(size[1], size[0], seed + 1), sr.scene.noise_rgba(size[0], size[0], seed + 2)]
-        if seed % 4 == 0:   # the vertex stage on its own: clip coordinates and window-space records, bit for bit
-            mesh = sr.create_mesh_from_data(dev, verts, idx)
-            clip, screen = mesh.vertex_stage(ubos[0], W, H)
-            rclip, rscreen = oracle.vertex_stage(ubos[0], verts, W, H)
-            mesh.destroy()
-            assert np.array_equal(clip.view(np.uint32), rclip.view(np.uint32)), f"seed {seed}: clip coordinates differ"
-            for field in ("X", "Y", "z", "rw"):
-                assert np.array_equal(screen[field].view(np.uint32), rscreen[field].view(np.uint32)), f"seed {seed}: window-space {field} differs"
-        got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples, rect=rect)
-        ref_dropped = ref_clipped = 0
-        for v in range(n_views):
-            ref = oracle.draw(ubos[v], verts, idx, images, W, H, samples, rect=rect)
-            what = f"seed {seed} view {v}: {idx.size // 3} triangles, {W}x{H}x{samples}, rect {rect}"
-            assert np.array_equal(got[v]["tri"], ref["tri"]), what + f": triangle ids differ at {int((got[v]['tri'] != ref['tri']).sum())} samples"
-            assert np.array_equal(got[v]["depth"].view(np.uint32), ref["depth"].view(np.uint32)), what + ": depth bits differ"
-            ref_dropped += ref["stats"]["tris_clip_culled"]; ref_clipped += ref["stats"]["tris_clipped"]
-            covered = int((ref["tri"] != 0xFFFFFFFF).any(axis=-1).sum())
-            frac, worst = util.color_match_fraction(got[v]["bgra"], ref["bgra"], 1)
-            if covered >= 2000:
-                worst_frac = min(worst_frac, frac)
-                # The default shading kernel computes one barycentric weight as 1 - (the other two): on a triangle with a
-                # vertex far outside the frame and almost on the eye plane that loses it (seed 136); the "exact_shading"
-                # variant does not have this weakness and is held to the bar on every frame.
-                if "exact_shading" in os.environ.get("SR_VARIANT", "") or "anisotropic" in os.environ.get("SR_VARIANT", "") or near_clip:
-                    assert frac >= 0.999, what + f": colour within 1 LSB on {frac:.5f} (worst {worst})"
-                elif frac < 0.999:
-                    print(what + f": colour within 1 LSB on {frac:.5f} (worst {worst}) -- default shading kernel, known limitation")
-            st = got[v]["stats"]
-        total_clipped += ref_clipped; total_dropped += ref_dropped
-        if near_clip:   # with the clipper on: dropped are only those it gives up on
-            assert st["triangles_unprojectable"] == ref_dropped and st["triangles_clipped"] == ref_clipped, f"seed {seed}: dropped / clipped counts {st} vs {ref_dropped}, {ref_clipped}"
-        else:
-            assert st["triangles_unprojectable"] == sum(ref_unproj(ubos[v], verts, idx, W, H, oracle) for v in range(n_views)), f"seed {seed}: unprojectable count"
-    print(f"ok: seeds {first}..{first + count - 1}, lowest colour fraction on well-covered frames {worst_frac:.5f}" +
-          (f"; near-plane clipper: {total_clipped} triangles clipped, {total_dropped} given up" if near_clip else ""))
-
-
-def ref_unproj(ubo, verts, idx, W, H, oracle):
-    """Triangles with one or two (not three) unprojectable vertices, from the oracle's vertex stage."""
-    _, screen = oracle.vertex_stage(ubo, verts, W, H)
-    bad = (screen["rw"] == 0.0)[idx.reshape(-1, 3)].sum(axis=1)
-    return int(((bad > 0) & (bad < 3)).sum())
+        lowest, clipped, dropped = check_seed(seed, sr, oracle, dev, util, vertex_stage_too=seed % 4 == 0)
+        worst_frac = min(worst_frac, lowest)
+        total_clipped += clipped; total_dropped += dropped
+    print(f"ok: seeds {first}..{first + count - 1}, lowest colour fraction on well-covered frames {worst_frac:.5f}"
+          f"; near-plane clipper: {total_clipped} triangles clipped, {total_dropped} given up")
 
 
 if __name__ == "__main__":

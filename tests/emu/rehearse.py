@@ -18,7 +18,7 @@ def main():
     import softraster
     softraster.LIB_PATH = build_emu.build()
     import bench
-    for workload in ("small_1080p_124ktri", "c1_800x600_msaa4"):
+    for workload in ("small_1080p_124ktri", "c1_800x600_msaa4", "c5_small"):
         sys.argv = ["bench.py", "--workload", workload, "--steps", "2", "--warmup", "1", "--cpu-threads", "4"]
         buf = io.StringIO()
         with redirect_stdout(buf):

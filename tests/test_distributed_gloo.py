@@ -1,4 +1,4 @@
-"""The N > 1 paths on CPU: world_size-2 gloo process groups.  The renderer of each rank is the CPU
+"""The N > 1 paths on CPU: gloo process groups of 2 and 4 ranks.  The renderer of each rank is the CPU
 oracle here (there is no GPU in this environment); what is under test is the host-side sharding and
 compositing of softraster.distributed: bands tile the frame, the gathered composite is bit-identical
 to the single-process frame, views are dealt round robin."""
@@ -38,6 +38,34 @@ def _worker(rank, world, port, mode, q):
             if rank == 0:
                 full = oracle.draw(ubo, verts, idx, tex, W, H, samples=1)
                 q.put(bool(np.array_equal(frame.numpy(), full["bgra"])))
+        elif mode == "balanced_pipelined":
+            # cost-balanced bands from the first frame's coverage, then three frames of a moving camera through the
+            # two-slot compositor: the exchange of a frame is still in flight while the next one is rendered
+            ubos = scene.orbit_ubos(3, W, H)
+            even = d.split_bands(W, H, world, align=8)
+            mine = oracle.draw(ubos[0], verts, idx, tex, W, H, rect=even[rank], shade=False)
+            rows = torch.zeros(H, dtype=torch.float64)
+            rows[even[rank][1]:even[rank][1] + even[rank][3]] = torch.from_numpy((mine["tri"][..., 0] != 0xFFFFFFFF).sum(axis=1).astype(np.float64))
+            dist.all_reduce(rows)           # every rank learns the whole profile and derives the same bands
+            bands = d.balance_bands(W / 8 + rows.numpy(), W, world, align=8)
+            comp = d.BandCompositor(bands, rank, world, "cpu", dst=0, slots=2)
+            ok = sum(b[3] for b in bands) == H and all(b[3] > 0 for b in bands)
+            frames = []
+            for f in range(3):
+                slot = f % 2
+                comp.wait(slot)             # the slot's previous exchange (frame f - 2) is over: it may be drawn into again
+                if rank == 0 and f >= 2:
+                    frames.append(comp.frame(slot).numpy().copy())
+                comp.local(slot).copy_(torch.from_numpy(oracle.draw(ubos[f], verts, idx, tex, W, H, rect=bands[rank])["bgra"]))
+                comp.exchange(slot)
+            for f in (1, 2):
+                comp.wait(f % 2)
+                if rank == 0:
+                    frames.append(comp.frame(f % 2).numpy().copy())
+            if rank == 0:
+                for f in range(3):
+                    ok = ok and bool(np.array_equal(frames[f], oracle.draw(ubos[f], verts, idx, tex, W, H)["bgra"]))
+                q.put(ok)
         else:   # sort-last by view
             n_views = 5
             ubos = scene.orbit_ubos(n_views, W, H)
@@ -53,12 +81,13 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sort_first", "sort_last"])
-def test_two_ranks(mode):
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("mode", ["sort_first", "sort_last", "balanced_pipelined"])
+def test_ranks(mode, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (0 if mode == "sort_first" else 1)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + ["sort_first", "sort_last", "balanced_pipelined"].index(mode) * 2 + world // 4
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -79,3 +108,24 @@ def test_band_and_view_partitions():
     assert all(b[1] % 64 == 0 for b in b8) and max(b[3] for b in b8) - min(b[3] for b in b8) <= 64
     assert sorted(sum((d.shard_views(1024, r, 8) for r in range(8)), [])) == list(range(1024))
     assert d.shard_views(5, 1, 2) == [1, 3] and d.shard_views(3, 7, 8) == []
+
+
+def test_balanced_bands():
+    _setup_paths()
+    from softraster import distributed as d
+    H, W = 4320, 7680
+    rows = np.zeros(H)
+    rows[590:3730] = np.sqrt(np.maximum(0.0, 1570.0 ** 2 - (np.arange(590, 3730) - 2160.0) ** 2)) * 2     # chord lengths of the benchmark's disc
+    cost = W / 8 + rows
+    for n in (2, 4, 8):
+        bands = d.balance_bands(cost, W, n)
+        assert len(bands) == n and bands[0][1] == 0 and sum(b[3] for b in bands) == H and all(b[3] > 0 for b in bands)
+        assert all(bands[r][1] + bands[r][3] == bands[r + 1][1] for r in range(n - 1)) and all(b[1] % 64 == 0 for b in bands)
+        shares = [cost[b[1]:b[1] + b[3]].sum() / cost.sum() for b in bands]
+        even = [cost[b[1]:b[1] + b[3]].sum() / cost.sum() for b in d.split_bands(W, H, n)]
+        assert max(shares) < 1.15 / n, (n, shares)
+        if n == 8:
+            assert max(even) > 1.5 / n     # what equal heights would give: the middle ranks carry the disc
+    assert d.balance_bands(np.zeros(100), 64, 4) == d.split_bands(64, 100, 4)
+    few = d.balance_bands([0, 0, 0, 5.0], 16, 4, align=64)
+    assert [b[3] for b in few] == [1, 1, 1, 1]

@@ -39,8 +39,9 @@ def build_emulation_library():
     build_emu.build()   # once, before child processes race to build it
 
 
-VARIANTS = ["fused_geometry,exact_shading", "sparse_tail_force,dirty_blocks", "cluster_cull_verify",
-            "cluster_cull,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic", "near_clip"]
+# device-level knobs under which every frame must stay the same: smaller tiles, the 512-work-item form of the 4-sample
+# tile kernel, a tile reference list that overflows on every first frame, a scratch budget that splits batches into passes
+KNOBS = [dict(SR_TILE_LOG2="5"), dict(SR_RASTER_HALF="1"), dict(SR_REF_CAPACITY="16"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4")]
 _child_runs = {}
 
 
@@ -54,12 +55,9 @@ def child_runs():
     full = os.path.join("tests", "test_gpu_zz_full_size.py")
     # (the 64-view, 8K and 16K configurations of that file run at reduced size in the other suites: at full size they take minutes here)
     full_size = dict(what=full, select="not config and not largest", SR_EMULATE_FULL_SIZE="1", HIPEMU_FUZZ_ULP="1")
-    _child_runs["full_size"] = [start_gpu_suite_emulated(**full_size),
-                                start_gpu_suite_emulated(SR_VARIANT="cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading", **full_size)]
+    _child_runs["full_size"] = [start_gpu_suite_emulated(**full_size)]
     _child_runs["default"] = [start_gpu_suite_emulated("forward"), start_gpu_suite_emulated("reverse", select=subset), start_gpu_suite_emulated("shuffle", select=subset)]
-    _child_runs["variants"] = [start_gpu_suite_emulated("forward", SR_VARIANT=v) for v in VARIANTS]
-    _child_runs["variants"].append(start_gpu_suite_emulated("reverse", select="reused or soup or golden or zz_full or huge or cluster or near_plane",
-                                                            SR_VARIANT="cluster_cull,sparse_tail_force,dirty_blocks,exact_shading,near_clip"))
+    _child_runs["knobs"] = [start_gpu_suite_emulated("forward", **k) for k in KNOBS]
     return _child_runs
 
 
@@ -69,24 +67,22 @@ def test_gpu_parity_suite_on_emulated_kernels():
     shuffled order between synchronisation points (a missing barrier or an order-dependent reservation
     shows up as a parity failure)."""
     tails = [finish(r) for r in child_runs()["default"]]
-    # the two tests that need a real GPU process and the two cases of the near_clip variant's own test are the only
-    # ones allowed to be skipped
-    assert "4 skipped" in tails[0], tails[0]
+    # the two tests that need a real GPU process are the only ones allowed to be skipped
+    assert "2 skipped" in tails[0], tails[0]
 
 
-def test_pipeline_variants_give_the_same_frames():
-    """The switchable pipeline variants (environment variable SR_VARIANT, see sr_api.hip) must pass the
-    same parity suite as the default pipeline; the combination of all of them also with the lanes in
-    descending order."""
-    for r in child_runs()["variants"]:
+def test_device_knobs_give_the_same_frames():
+    """Tile size, workgroup size of the 4-sample tile kernel, initial size of the tile reference list and the scratch
+    budget are per-device settings (environment variables read by sr_device_create) that must not change a frame:
+    the whole parity suite under each of them."""
+    for r in child_runs()["knobs"]:
         finish(r)
 
 
 def test_full_size_frame_on_emulated_kernels():
     """The 10 M-triangle 3840x2160 frame of the headline benchmark, executed on the CPU (about a
     minute), with every result of the hardware's approximate reciprocal / rsqrt / exp2 / log2 moved
-    by up to one ulp: windows against the oracle plus the whole-frame properties -- on the default
-    pipeline and on the combination of all variants."""
+    by up to one ulp: the whole frame against the oracle plus the whole-frame properties."""
     for r in child_runs()["full_size"]:
         finish(r)
 
@@ -159,43 +155,41 @@ np.save({str(tmp_path / 'py_keys.npy')!r}, tgt.read_color(0))
 def test_scene_driver_under_address_and_ub_sanitizers():
     """tests/emu/asan_scenes.cpp: spheres and triangle soups through the C ABI, 1 and 4 samples, several
     views, restricted rectangles, every target drawn twice -- kernels and host code under AddressSanitizer
-    (workgroup-local arrays and the heap) and UndefinedBehaviorSanitizer, for the default pipeline and for
-    the variants.  Any report fails the run."""
+    (workgroup-local arrays and the heap) and UndefinedBehaviorSanitizer, with the default settings and with the
+    device knobs.  Any report fails the run."""
     build_emulation_library()
     import build_emu
     exe = build_emu.build_sanitized()
     env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    runs = [(v, subprocess.Popen([exe], env=dict(env, SR_VARIANT=v), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-            for v in ("", "cluster_cull_verify,sparse_tail,dirty_blocks,exact_shading,raster_512,near_clip", "anisotropic,sparse_tail_force,cluster_cull", "near_clip")]
-    for v, proc in runs:
+    runs = [(k, subprocess.Popen([exe], env=dict(env, **k), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+            for k in ({}, dict(SR_TILE_LOG2="5", SR_RASTER_HALF="1"), dict(SR_REF_CAPACITY="16", SR_SCRATCH_MIB="1"))]
+    for k, proc in runs:
         out, _ = proc.communicate(timeout=1200)
-        assert proc.returncode == 0 and "ok: 32 draws" in out and "runtime error" not in out and "AddressSanitizer" not in out, f"variant '{v}':\n{out[-3000:]}"
+        assert proc.returncode == 0 and "ok: 32 draws" in out and "runtime error" not in out and "AddressSanitizer" not in out, f"knobs {k}:\n{out[-3000:]}"
 
 
 def test_differential_fuzzing_against_the_oracle():
     """tests/emu/fuzz_parity.py, a short run of each kind: random soups, dust, slivers and strips under
     random matrices, cameras (some inside the cloud), frame sizes, sample counts, rectangles and view
-    counts.  Visibility is bit-exact and the unprojectable counter matches on every scene; colour meets
-    the bar on every scene for the exact-shading variants (the default shading kernel's known weakness on
-    near-eye-plane vertices is only reported)."""
+    counts.  Visibility is bit-exact, the clipped and given-up counters match and colour meets the bar on every
+    scene, with trilinear and with 16x anisotropic samplers."""
     build_emulation_library()
     script = os.path.join(ROOT, "tests", "emu", "fuzz_parity.py")
-    runs = [(v, subprocess.Popen([sys.executable, script, str(first), "24"], env=dict(os.environ, SR_VARIANT=v), stdout=subprocess.PIPE,
-                                 stderr=subprocess.STDOUT, text=True))
-            for v, first in (("", 0), ("exact_shading", 100), ("cluster_cull_verify,sparse_tail_force,dirty_blocks,exact_shading", 2300), ("anisotropic", 300),
-                             ("near_clip,dirty_blocks", 3400), ("near_clip", 3500))]
-    for v, proc in runs:
+    runs = [(a, first, subprocess.Popen([sys.executable, script, str(first), "24"], env=dict(os.environ, SR_FUZZ_ANISOTROPIC=a), stdout=subprocess.PIPE,
+                                        stderr=subprocess.STDOUT, text=True))
+            for a, first in (("0", 0), ("0", 100), ("0", 2300), ("1", 300), ("0", 3400), ("1", 3500))]
+    for a, first, proc in runs:
         out, _ = proc.communicate(timeout=1500)
-        assert proc.returncode == 0 and "ok: seeds" in out, f"variant '{v}':\n{out[-3000:]}"
+        assert proc.returncode == 0 and "ok: seeds" in out, f"anisotropic {a}, first seed {first}:\n{out[-3000:]}"
 
 
 def test_benchmark_and_smoke_scripts_run_end_to_end():
-    """tests/emu/rehearse.py: bench.py (two small workloads, one process) and __graft_entry__.smoke() against the CPU build
+    """tests/emu/rehearse.py: bench.py (three small workloads, one process) and __graft_entry__.smoke() against the CPU build
     of the kernels -- the scripts the round-end driver runs on the GPU box still produce their JSON line and their
     oracle comparison with the current library."""
     build_emulation_library()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "rehearse.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert r.returncode == 0 and r.stdout.count("bench ok:") == 2 and r.stdout.strip().endswith("smoke ok"), r.stdout[-3000:]
+    assert r.returncode == 0 and r.stdout.count("bench ok:") == 3 and r.stdout.strip().endswith("smoke ok"), r.stdout[-3000:]
 
 
 def test_file_readers_survive_mutated_files():

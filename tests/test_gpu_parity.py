@@ -4,6 +4,8 @@ Bar: clip coordinates, window-space vertex records, coverage, depth and triangle
 colour is within 1 LSB per 8-bit channel on >= 99.9 % of the pixels (the oracle uses libm powf/log2f,
 the kernels use the GPU's exp2/log2 instructions)."""
 import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -53,7 +55,7 @@ def test_vertex_stage_general_matrices_and_unprojectable(sr, oracle, device):
 
 @pytest.mark.parametrize("samples", [1, 4])
 @pytest.mark.parametrize("segments", [32, 88])
-def test_reference_frame_800x600(sr, oracle, device, segments, samples):
+def test_reference_frame_800x600(sr, oracle, device, segments, samples, anisotropic):
     """BASELINE config 1: one 800x600 frame of the bundled-model stand-in with the default camera."""
     verts, idx = sr.scene.uv_sphere(segments, segments)
     ubo = sr.scene.default_camera_ubo(800, 600)
@@ -65,7 +67,7 @@ def test_reference_frame_800x600(sr, oracle, device, segments, samples):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
-def test_triangle_soup_large_and_small_with_ties(sr, oracle, device, samples):
+def test_triangle_soup_large_and_small_with_ties(sr, oracle, device, samples, anisotropic):
     verts, idx = util.random_soup(6000, seed=11, size=0.8)
     ubo = sr.scene.default_camera_ubo(640, 360)
     images = sr.scene.material_textures(64, seed=5)
@@ -74,7 +76,7 @@ def test_triangle_soup_large_and_small_with_ties(sr, oracle, device, samples):
     _check_view(got, ref)
 
 
-def test_huge_triangles_cover_many_tiles(sr, oracle, device):
+def test_huge_triangles_cover_many_tiles(sr, oracle, device, anisotropic):
     verts, idx = sr.scene.screen_quad(z=0.0, half=30.0, uv_scale=40.0)
     ubo = sr.scene.default_camera_ubo(1920, 1080)
     images = sr.scene.material_textures(128)
@@ -83,8 +85,9 @@ def test_huge_triangles_cover_many_tiles(sr, oracle, device):
     _check_view(got, ref)
 
 
-def test_near_plane_crossing_is_dropped_and_counted(sr, oracle, device):
-    clipping = "near_clip" in os.environ.get("SR_VARIANT", "")
+def test_near_plane_crossing_is_clipped(sr, oracle, device):
+    """depthClampEnable = VK_FALSE (src/main.cpp:586): a quad that reaches behind the eye is cut at the near plane and
+    its visible part drawn, not dropped."""
     verts, idx = sr.scene.screen_quad(z=0.0, half=500.0)   # reaches behind the eye
     small, sidx = sr.scene.uv_sphere(16, 16)
     v = np.concatenate([verts, small]); i = np.concatenate([idx, sidx + 4]).astype(np.uint32)
@@ -93,13 +96,9 @@ def test_near_plane_crossing_is_dropped_and_counted(sr, oracle, device):
     got = util.gpu_render(sr, device, v, i, images, ubo, 320, 240, 1)[0]
     ref = oracle.draw(ubo, v, i, images, 320, 240, 1)
     _check_view(got, ref)
-    if clipping:   # the pipeline variant that clips them at the near plane instead
-        assert ref["stats"]["tris_clip_culled"] == 0 and ref["stats"]["tris_clipped"] == 2
-        assert got["stats"]["triangles_unprojectable"] == 0 and got["stats"]["triangles_clipped"] == 2
-        assert (got["tri"] < 2).sum() > 10000    # the quad now fills most of the frame
-    else:
-        assert ref["stats"]["tris_clip_culled"] == 2
-        assert got["stats"]["triangles_unprojectable"] == 2 and got["stats"]["triangles_clipped"] == 0
+    assert ref["stats"]["tris_clip_culled"] == 0 and ref["stats"]["tris_clipped"] == 2
+    assert got["stats"]["triangles_unprojectable"] == 0 and got["stats"]["triangles_clipped"] == 2
+    assert (got["tri"] < 2).sum() > 10000    # the quad fills most of the frame
 
 
 @pytest.mark.parametrize("samples", [1, 4])
@@ -200,45 +199,50 @@ def _random_view(rng, W, H, sr):
     return sr.scene.make_ubo(model, view, proj, eye)
 
 
-def test_cluster_culling_never_drops_a_drawn_triangle(sr, oracle, device):
-    """With the pipeline variant cluster_cull_verify the set-up kernel evaluates the cluster test but
-    skips nothing, and counts every triangle of a would-be-skipped cluster that the per-triangle path
-    draws or counts: that count must be zero for any mesh, matrix and camera.  (Without the variant
-    the count is zero by construction; the CPU suite runs this test with the variant on.)"""
-    rng = np.random.default_rng(11)
-    images = sr.scene.material_textures(16)
-    tex = [sr.create_texture(device, im) for im in images]
-    culled = 0
+def test_mesh_and_textures_destroyed_before_the_read_back(sr, oracle):
+    """The reference may destroy a mesh and its textures as soon as the device is idle.  Here a draw whose tile
+    reference list overflowed is re-issued when its target is next read -- which needs the mesh and the textures --
+    so destroying them first must complete that draw: the read-back and the counters afterwards are the oracle's."""
+    verts, idx = util.random_soup(300, 21, size=1.2)
+    W, H = 320, 200
+    ubo = sr.scene.default_camera_ubo(W, H)
+    images = sr.scene.material_textures(32)
+    os.environ["SR_REF_CAPACITY"] = "64"     # far too small: the first draw overflows and must be repeated
     try:
-        for case in range(10):
-            X, Y = int(rng.integers(40, 400)), int(rng.integers(30, 300))
-            verts, idx = sr.scene.uv_sphere(X, Y)
-            verts[:, 0:3] *= (1.0 + 0.02 * np.sin(7.0 * verts[:, 6:7] * 6.283) * np.cos(5.0 * verts[:, 7:8] * 3.1416)).astype(np.float32)   # bumps
-            if case % 3 == 2:   # reverse the winding: the inside of the shell faces the camera
-                idx = np.ascontiguousarray(idx.reshape(-1, 3)[:, ::-1]).reshape(-1)
-            mesh = sr.create_mesh_from_data(device, verts, idx)
-            W, H = [(320, 200), (640, 360), (1000, 700), (257, 129)][case % 4]
-            rect = None if case % 2 == 0 else (W // 5, H // 7, W // 2, H // 2)
-            tgt = sr.RenderTarget(device, W, H, samples=1 if case % 4 else 4, n_views=3, rect=rect)
-            try:
-                ubos = np.stack([_random_view(rng, W, H, sr) for _ in range(3)])
-                sr.draw(device, tgt, mesh, ubos, tex)
-                st = tgt.stats()
-                assert st["cull_violations"] == 0, (case, st)
-                culled += st["clusters_culled"]
-                if case < 3:   # and the frame itself is the oracle's
-                    for v in range(3):
-                        ref = oracle.draw(ubos[v], verts, idx, images, W, H, 1 if case % 4 else 4, rect=rect)
-                        util.assert_visibility_equal({"tri": tgt.read_triangle_ids(v), "depth": tgt.read_depth(v)}, ref)
-            finally:
-                tgt.destroy()
-                mesh.destroy()
+        dev = sr.Device(0)
     finally:
+        del os.environ["SR_REF_CAPACITY"]
+    try:
+        mesh = sr.create_mesh_from_data(dev, verts, idx)
+        tex = [sr.create_texture(dev, im) for im in images]
+        tgt = sr.RenderTarget(dev, W, H)
+        sr.draw(dev, tgt, mesh, ubo, tex)
+        mesh.destroy()
         for t in tex:
             t.destroy()
-    import os
-    if "cluster_cull" in os.environ.get("SR_VARIANT", ""):
-        assert culled > 0, "the variant is on but no cluster was ever skipped: the test checks nothing"
+        junk = sr.create_mesh_from_data(dev, np.zeros((3 * 4096, 8), np.float32), np.arange(3 * 4096, dtype=np.uint32))   # likely to reuse the freed memory
+        got = {"tri": tgt.read_triangle_ids(0), "depth": tgt.read_depth(0), "bgra": tgt.read_color(0)}
+        st = tgt.stats()
+        junk.destroy()
+        tgt.destroy()
+        _check_view(got, oracle.draw(ubo, verts, idx, images, W, H))
+        assert st["triangles"] == idx.size // 3 and st["vertices"] == verts.shape[0] and st["tile_refs"] > 64
+    finally:
+        dev.close()
+
+
+FUZZ_SEEDS_THAT_NEED_EXACT_SHADING = (199, 427, 613, 1040, 1236, 1414)   # found by running the fuzzer on the former shading pass
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS_THAT_NEED_EXACT_SHADING)
+def test_vertex_near_the_eye_plane_and_far_off_frame(sr, oracle, device, seed):
+    """Cases of the differential fuzzer (tests/emu/fuzz_parity.py) in which a visible triangle has a vertex far outside
+    the frame and almost on the eye plane: its 1/w is huge, and a shading pass that takes one barycentric weight as one
+    minus the other two, or recomputes the window-space vertices with an approximate reciprocal, colours such a triangle
+    wrongly (up to 60 % of a frame's pixels off the bar).  Visibility, clip counts and colour must all meet the bar."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import fuzz_parity
+    fuzz_parity.check_seed(seed, sr, oracle, device, util)
 
 
 def test_model_and_textures_from_files(sr, oracle, device, tmp_path):
@@ -280,7 +284,7 @@ def test_model_and_textures_from_files(sr, oracle, device, tmp_path):
             t.destroy()
 
 
-def test_multi_view_batch_matches_single_views(sr, oracle, device):
+def test_multi_view_batch_matches_single_views(sr, oracle, device, anisotropic):
     """BASELINE config 2 in small: a batch of orbit cameras drawn by one call."""
     verts, idx = sr.scene.uv_sphere(32, 32)
     ubos = sr.scene.orbit_ubos(6, 480, 270)
@@ -327,15 +331,13 @@ def _inward_sphere(sr, x_segments, y_segments, radius):
 
 @pytest.mark.parametrize("samples", [1, 4])
 def test_near_plane_clipper(sr, oracle, samples):
-    """Pipeline variant near_clip (skipped otherwise): triangles with a vertex behind the eye are cut at the near
-    plane and drawn, as the fixed-function clipper of the reference's pipeline does, instead of dropped.  A ground
+    """Triangles with a vertex behind the eye are cut at the near plane and drawn, as the fixed-function clipper of
+    the reference's pipeline does (depthClampEnable = VK_FALSE, src/main.cpp:586).  A ground
     quad that passes under and behind the camera, and a sphere seen from inside with the eye close to its surface
     (dozens of triangles reach from behind the eye to beyond the near plane, sharing their cut edges): visibility equals the oracle's
     clipper bit for bit, colour to the usual bar, in a three-view draw; then a clip list of 8 entries, where the
     triangles that find no room are dropped and counted."""
     import math
-    if "near_clip" not in os.environ.get("SR_VARIANT", ""):
-        pytest.skip("needs SR_VARIANT=near_clip")
     W, H = 256, 160
     images = sr.scene.material_textures(64, seed=4)
     ground = np.zeros((4, 8), np.float32)
@@ -465,7 +467,7 @@ def test_screen_split_is_partition_independent(sr, oracle, device, samples):
         _check_view(part, ref)
 
 
-def test_non_power_of_two_and_mixed_size_textures(sr, oracle, device):
+def test_non_power_of_two_and_mixed_size_textures(sr, oracle, device, anisotropic):
     rng = np.random.default_rng(2)
     images = [rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) for (w, h) in [(100, 37), (8, 8), (1, 64), (33, 5)]]
     verts, idx = sr.scene.uv_sphere(40, 30)
@@ -495,9 +497,7 @@ def test_golden_fixtures(sr, device):
         sc = make_golden.build_scene(name)
         g = np.load(make_golden.path_of(name))
         got = util.gpu_render(sr, device, sc["verts"], sc["idx"], sc["images"], sc["ubo"], sc["width"], sc["height"], sc["samples"])[0]
-        # the committed colours are isotropic: with the "anisotropic" pipeline variant only visibility is comparable
-        import os
-        _check_view(got, {"tri": g["tri"], "depth": g["depth"], "bgra": g["bgra"]}, check_color="anisotropic" not in os.environ.get("SR_VARIANT", ""))
+        _check_view(got, {"tri": g["tri"], "depth": g["depth"], "bgra": g["bgra"]})   # (the committed colours are trilinear, like the session's default sampler)
 
 
 def test_cpp_host_app_matches_python_host(sr, device, tmp_path):

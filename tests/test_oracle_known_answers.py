@@ -150,11 +150,15 @@ def test_standard_4x_sample_positions(oracle):
     assert half[3] == 255
 
 
-def test_unprojectable_triangles_are_dropped_and_counted(oracle):
+def test_unprojectable_triangles_without_the_clipper_are_dropped_and_counted(oracle):
     W, H = 32, 32
     ubo = scene.default_camera_ubo(W, H)
-    v, i = scene.screen_quad(z=0.0, half=500.0)           # spans behind the eye: would need clipping
-    r = oracle.draw(ubo, v, i, TEX, W, H)
+    v, i = scene.screen_quad(z=0.0, half=500.0)           # spans behind the eye: needs clipping
+    oracle.set_near_clip(False)
+    try:
+        r = oracle.draw(ubo, v, i, TEX, W, H)
+    finally:
+        oracle.set_near_clip(True)    # what the session's other tests expect
     assert r["stats"]["tris_clip_culled"] == 2 and (r["tri"] == 0xFFFFFFFF).all()
     behind, i = scene.screen_quad(z=0.0, half=1.0)
     behind[:, 0:3] += (10, 10, 10)                          # entirely behind the eye: silently invisible
@@ -190,7 +194,7 @@ def test_near_plane_clipper_against_a_ray_cast(oracle, half):
         r = oracle.draw(ubo, quad(-half), idx, tex, W, H, 1, threads=4)
         short = oracle.draw(ubo, quad(-1.0), idx, tex, W, H, 1, threads=4)
     finally:
-        oracle.set_near_clip("near_clip" in os.environ.get("SR_VARIANT", ""))   # what the session's other tests expect
+        oracle.set_near_clip(True)   # what the session's other tests expect
     assert r["stats"]["tris_clipped"] == 2 and r["stats"]["tris_clip_culled"] == 0
     # the same frame by ray casting, in double precision
     pv = proj.astype(np.float64) @ view.astype(np.float64)

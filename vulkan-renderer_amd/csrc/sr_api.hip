@@ -49,54 +49,7 @@ struct DeviceBuffer {
 };
 
 constexpr int kNumStageEvents = 9;   // start, clear, vertex, setup, bin, scan, fill, raster, fragment
-constexpr int kCountersPerPass = 8;  // total refs, dropped refs, unprojectable triangles, binned triangles, micro-triangles, spare
-
-// Pipeline variants that can be switched on per device with the environment variable SR_VARIANT
-// (comma-separated names).  They produce the same frames as the default pipeline (the parity tests
-// run with each of them); they exist so that alternatives can be timed against each other on the GPU.
-enum : unsigned {
-    kVariantFusedGeometry = 1u << 0,   // "fused_geometry": triangle set-up transforms the vertices itself, no vertex pass
-    kVariantDirtyBlocks = 1u << 1,     // "dirty_blocks": per-block dirty map; only written blocks are cleared and read back by shading
-                                       //                 (the marking lives in the fused set-up kernel, so this implies fused_geometry)
-    kVariantExactShading = 1u << 2,    // "exact_shading": the shading pass recomputes window-space vertices bit-identically to the vertex stage
-    kVariantSparseTail = 1u << 3,      // "sparse_tail": a target whose last frame left few triangles for the tile lists gets one kernel
-                                       //                in place of bin + scan + fill + raster (implies fused_geometry)
-    kVariantSparseTailForce = 1u << 4, // "sparse_tail_force": always take that kernel, whatever the last frame was (for tests)
-    kVariantClusterCull = 1u << 5,     // "cluster_cull": skip 64-triangle clusters that provably draw nothing (sr_device.h; implies fused_geometry)
-    kVariantAnisotropic = 1u << 7,     // "anisotropic": the sampler's maxAnisotropy (src/texture.cpp:255-256) is applied, by the method the
-                                       //                Vulkan specification spells out (implies dirty_blocks, exact_shading, fused_geometry)
-    kVariantRaster512 = 1u << 8,       // "raster_512": the 4-sample tile kernel runs 512 work-items per 32x32 tile; at 1024 it is capped at
-                                       //               128 registers and spills 500 bytes per work-item
-    kVariantNearClip = 1u << 9,        // "near_clip": triangles with a vertex that cannot be projected are clipped against the near plane
-                                       //              (sr_device.h) instead of dropped (implies exact_shading)
-    kVariantClusterVerify = 1u << 6,   // "cluster_cull_verify": evaluate the cluster test but skip nothing; count what skipped clusters
-                                       //                        would have drawn into sr_draw_stats.cull_violations (for tests)
-};
-// a frame qualifies for the sparse tail when its predecessor stayed under these
-constexpr uint32_t kSparseMaxPending = 4096, kSparseMaxRefs = 16384, kSparseMaxSteps = 65536;
-
-unsigned parse_variants(const char* text)
-{
-    unsigned v = 0;
-    const std::string s = text ? text : "";
-    size_t pos = 0;
-    while (pos <= s.size()) {
-        const size_t end = std::min(s.find(',', pos), s.size());
-        const std::string name = s.substr(pos, end - pos);
-        if (name == "fused_geometry") v |= kVariantFusedGeometry;
-        if (name == "dirty_blocks") v |= kVariantDirtyBlocks | kVariantFusedGeometry;
-        if (name == "exact_shading") v |= kVariantExactShading;
-        if (name == "raster_512") v |= kVariantRaster512;
-        if (name == "near_clip") v |= kVariantNearClip | kVariantExactShading;
-        if (name == "anisotropic") v |= kVariantAnisotropic | kVariantExactShading | kVariantDirtyBlocks | kVariantFusedGeometry;
-        if (name == "cluster_cull") v |= kVariantClusterCull | kVariantFusedGeometry;
-        if (name == "cluster_cull_verify") v |= kVariantClusterVerify | kVariantClusterCull | kVariantFusedGeometry;
-        if (name == "sparse_tail") v |= kVariantSparseTail | kVariantFusedGeometry;
-        if (name == "sparse_tail_force") v |= kVariantSparseTailForce | kVariantSparseTail | kVariantFusedGeometry;
-        pos = end + 1;
-    }
-    return v;
-}
+constexpr int kCountersPerPass = 8;  // words per pass the scan kernel writes for the host: total refs, -, unprojectable, binned, micro, -, clipped, -
 
 }  // namespace
 
@@ -106,8 +59,8 @@ struct sr_device_t {
     float* d_decode = nullptr;   // 256
     float* d_thresh = nullptr;   // 255 (+1 pad)
     // scratch reused by every draw on this device (in-order on `stream`)
-    DeviceBuffer screen, tile_count, tile_offset, survivors, survivor_count, refs, views, counters;
-    DeviceBuffer clip;           // kVariantNearClip: [state: 4 words][entries: capacity x 8 bytes]
+    DeviceBuffer screen, tile_count, tile_offset, records, pending, refs, views;
+    DeviceBuffer clip;           // entries of the near-plane clip list: capacity x 8 bytes
     uint32_t clip_capacity = 65536;   // triangles per pass that can be clipped; more are dropped and counted
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
@@ -117,18 +70,15 @@ struct sr_device_t {
     uint64_t ref_capacity = 0;
     size_t scratch_budget = (size_t)16 << 30;
     int tile_log2_override = 0;
-    unsigned variants = 0;       // kVariant* bits, from SR_VARIANT
-    uint32_t* d_cull_violations = nullptr;   // kVariantClusterVerify: one counter, accumulated over the passes of a draw
+    bool raster_half = false;    // SR_RASTER_HALF=1: the 4-sample tile kernel runs 512 work-items per 32x32 tile (measurement switch)
     bool profiling = false;
     std::vector<hipEvent_t> events;   // kNumStageEvents per pass of the last profiled draw
     size_t events_used = 0;
+    std::vector<sr_target_t*> targets;   // live targets of this device (they may hold a reference to a mesh and textures)
 };
 
 struct sr_mesh_t {
     void* d_aos = nullptr;
-    void* d_pos4 = nullptr;      // packed (x, y, z, 1) positions; only with kVariantFusedGeometry
-    ClusterRec* d_clusters = nullptr;   // kVariantClusterCull: one record per kClusterTris consecutive triangles
-    uint32_t n_clusters = 0;
     float *px = nullptr, *py = nullptr, *pz = nullptr;
     uint32_t* d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
@@ -151,21 +101,19 @@ struct sr_target_t {
     FrameGeom g{};
     uint32_t n_views = 0;
     uint64_t* d_vis = nullptr;
-    DirtyMap dirty{nullptr, 0, 0};   // kVariantDirtyBlocks: flags for all views of the target
     uint32_t* d_color_own = nullptr;
     uint32_t* d_color = nullptr;
-    // the last draw, kept so that it can be re-issued if the reference list was too small
+    // the last draw, kept so that it can be re-issued if the reference list was too small; mesh and textures are
+    // referenced only while check_pending is set (destroying one of them resolves the draw first)
     bool drawn = false, check_pending = false;
     sr_mesh mesh = nullptr;
     sr_texture tex[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t mesh_verts = 0, mesh_tris = 0;   // of the last draw's mesh (it may be gone when the counters are asked for)
     std::vector<ViewXform> views;
-    std::vector<ViewCull> cull_views;   // kVariantClusterCull: one per view, staged behind the transforms
     uint32_t passes = 0;
     uint32_t* h_counters = nullptr; void* hd_counters = nullptr; size_t h_counters_cap = 0;   // pinned + mapped, [passes][8], written by the scan kernel of the last draw
     uint64_t capacity_at_draw = 0;
     uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0, clipped = 0;
-    bool sparse = false;        // kVariantSparseTail: the draw being issued (and then: the last draw) uses the sparse tail
-    uint64_t cull_violations = 0;   // kVariantClusterVerify: of the last draw
 };
 
 namespace {
@@ -184,6 +132,7 @@ TexDesc make_tex_desc(const sr_texture_t* t)
     d.min_lod = t->samp.min_lod;
     d.max_lod = t->samp.max_lod < 0.0f ? (float)t->levels : t->samp.max_lod;
     d.bias = t->samp.mip_lod_bias;
+    d.max_aniso = t->samp.max_anisotropy;
     std::memcpy(d.level_off, t->level_off, sizeof d.level_off);
     return d;
 }
@@ -209,100 +158,6 @@ uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameG
     return (uint32_t)std::max<uint64_t>(v, 1);
 }
 
-// One record per kClusterTris consecutive triangles (sr_device.h).  Double precision; the float results are
-// widened on the safe side (larger sphere, wider cone, smaller inradius and perimeter).
-std::vector<ClusterRec> build_clusters(const float* verts /* 8 floats per vertex */, const uint32_t* idx, uint32_t n_tris)
-{
-    const uint32_t n_clusters = (n_tris + kClusterTris - 1) / kClusterTris;
-    std::vector<ClusterRec> out(n_clusters);
-    std::vector<double> normals;
-    for (uint32_t c = 0; c < n_clusters; ++c) {
-        const uint32_t t0 = c * kClusterTris, t1 = std::min(n_tris, t0 + kClusterTris);
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (uint32_t t = t0; t < t1; ++t)
-            for (int k = 0; k < 3; ++k) {
-                const float* p = verts + 8 * (size_t)idx[3 * (size_t)t + k];
-                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)p[a]); hi[a] = std::max(hi[a], (double)p[a]); }
-            }
-        const double ctr[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
-        double r2 = 0.0, sum[3] = {0, 0, 0}, rho_min = 1e300, p_min = 1e300;
-        bool usable = true;
-        normals.clear();
-        for (uint32_t t = t0; t < t1; ++t) {
-            const float* pf[3];
-            double p[3][3];
-            for (int k = 0; k < 3; ++k) {
-                pf[k] = verts + 8 * (size_t)idx[3 * (size_t)t + k];
-                for (int a = 0; a < 3; ++a) p[k][a] = pf[k][a];
-                const double d2 = (p[k][0] - ctr[0]) * (p[k][0] - ctr[0]) + (p[k][1] - ctr[1]) * (p[k][1] - ctr[1]) + (p[k][2] - ctr[2]) * (p[k][2] - ctr[2]);
-                r2 = std::max(r2, d2);
-            }
-            auto same = [&](int i, int j) { return pf[i][0] == pf[j][0] && pf[i][1] == pf[j][1] && pf[i][2] == pf[j][2]; };
-            if (same(0, 1) || same(1, 2) || same(0, 2)) continue;   // two corners coincide: the snapped triangle has zero area whatever the view
-            const double e1[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]}, e2[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
-            const double e3[3] = {p[2][0] - p[1][0], p[2][1] - p[1][1], p[2][2] - p[1][2]};
-            const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-            const double a2 = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-            const double per = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) + std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]) +
-                               std::sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
-            if (!(a2 > 1e-12 * per * per)) { usable = false; continue; }   // collinear corners: facing is decided by rounding, never skip
-            for (int a = 0; a < 3; ++a) { normals.push_back(n[a] / a2); sum[a] += n[a] / a2; }
-            rho_min = std::min(rho_min, a2 / per);
-            p_min = std::min(p_min, per);
-        }
-        ClusterRec& rec = out[c];
-        rec.cx = (float)ctr[0]; rec.cy = (float)ctr[1]; rec.cz = (float)ctr[2];
-        rec.r = (float)(std::sqrt(r2) * 1.00001 + 1e-30) + 1e-6f * (std::fabs(rec.cx) + std::fabs(rec.cy) + std::fabs(rec.cz));   // covers the rounding of the centre
-        rec.ax = rec.ay = rec.az = 0.0f; rec.cos_alpha = -2.0f; rec.sin_alpha = 0.0f; rec.rho_min = 0.0f; rec.p_min = 1.0f; rec.pad = 0.0f;
-        const double sl = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
-        if (usable && !normals.empty() && sl > 1e-3 * (double)(normals.size() / 3)) {
-            const double ax[3] = {sum[0] / sl, sum[1] / sl, sum[2] / sl};
-            double cmin = 1.0;
-            for (size_t i = 0; i < normals.size(); i += 3) cmin = std::min(cmin, normals[i] * ax[0] + normals[i + 1] * ax[1] + normals[i + 2] * ax[2]);
-            cmin -= 1e-5;   // the float axis and the device's float arithmetic
-            if (cmin > 0.05) {
-                rec.ax = (float)ax[0]; rec.ay = (float)ax[1]; rec.az = (float)ax[2];
-                rec.cos_alpha = (float)cmin; rec.sin_alpha = (float)std::sqrt(1.0 - cmin * cmin) * 1.00001f;
-                rec.rho_min = (float)(rho_min * 0.9999); rec.p_min = (float)(p_min * 0.9999);
-            }
-        }
-    }
-    return out;
-}
-
-// per-view constants of the cluster test, from the same float matrices the kernels use
-ViewCull make_view_cull(const ViewXform& x)
-{
-    double M[16], PV[16], T[16];
-    for (int i = 0; i < 16; ++i) { M[i] = x.model[i]; PV[i] = x.pv[i]; }
-    for (int c = 0; c < 4; ++c)
-        for (int r = 0; r < 4; ++r) { double s = 0; for (int k = 0; k < 4; ++k) s += PV[4 * k + r] * M[4 * c + k]; T[4 * c + r] = s; }   // column-major PV * M
-    auto row = [&](int r, double* v, double& t) { v[0] = T[r]; v[1] = T[4 + r]; v[2] = T[8 + r]; t = T[12 + r]; };
-    double R0[3], R1[3], R3[3], t0, t1, t3;
-    row(0, R0, t0); row(1, R1, t1); row(3, R3, t3);
-    const double det = R0[0] * (R1[1] * R3[2] - R1[2] * R3[1]) - R0[1] * (R1[0] * R3[2] - R1[2] * R3[0]) + R0[2] * (R1[0] * R3[1] - R1[1] * R3[0]);
-    auto len = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-    ViewCull c{};
-    for (int a = 0; a < 3; ++a) { c.R0[a] = (float)R0[a]; c.R1[a] = (float)R1[a]; c.R3[a] = (float)R3[a]; }
-    c.t0 = (float)t0; c.t1 = (float)t1; c.t3 = (float)t3;
-    c.nR0 = (float)(len(R0) * 1.000001); c.nR1 = (float)(len(R1) * 1.000001); c.nR3 = (float)(len(R3) * 1.000001);
-    c.sigma = det < 0 ? -1.0f : 1.0f;
-    c.absdet = (float)(std::fabs(det) * 0.999999);
-    c.cone_ok = 0.0f;
-    const double scale = len(R0) * len(R1) * len(R3);
-    if (std::fabs(det) > 1e-9 * scale && scale > 0) {
-        // centre of projection: P e + t = 0 (Cramer)
-        const double b0 = -t0, b1 = -t1, b3 = -t3;
-        const double ex = (b0 * (R1[1] * R3[2] - R1[2] * R3[1]) - R0[1] * (b1 * R3[2] - R1[2] * b3) + R0[2] * (b1 * R3[1] - R1[1] * b3)) / det;
-        const double ey = (R0[0] * (b1 * R3[2] - R1[2] * b3) - b0 * (R1[0] * R3[2] - R1[2] * R3[0]) + R0[2] * (R1[0] * b3 - b1 * R3[0])) / det;
-        const double ez = (R0[0] * (R1[1] * b3 - b1 * R3[1]) - R0[1] * (R1[0] * b3 - b1 * R3[0]) + b0 * (R1[0] * R3[1] - R1[1] * R3[0])) / det;
-        if (std::isfinite(ex) && std::isfinite(ey) && std::isfinite(ez) && std::fabs(ex) + std::fabs(ey) + std::fabs(ez) < 1e15) {
-            c.e[0] = (float)ex; c.e[1] = (float)ey; c.e[2] = (float)ez; c.cone_ok = 1.0f;
-        }
-    }
-    return c;
-}
-
 // issues every kernel of one draw (all passes) on the device's stream
 int issue_draw(sr_device_t* dev, sr_target_t* tg)
 {
@@ -317,24 +172,21 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     if (dev->ref_capacity == 0) dev->ref_capacity = std::max<uint64_t>((uint64_t)m->n_tris * vpp, (uint64_t)1 << 20);
     dev->ref_capacity = std::min<uint64_t>(dev->ref_capacity, 0xFFFFFFFFull);
 
-    // three per-tile counter arrays of a pass, cleared by one memset; [block_count: vpp*n_blocks]
-    // follows and is fully written by the set-up kernel
     const uint32_t bt = setup_block_triangles();
-    const uint32_t n_blocks = (m->n_tris + bt - 1u) / bt;
+    const uint32_t n_blocks = std::max((m->n_tris + bt - 1u) / bt, 1u);
+    const uint32_t pending_stride = n_blocks * bt;
     const size_t count_words = (size_t)vpp * n_tiles * 3;
     SR_HIP(dev->screen.ensure((size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex)));
-    // layout of the binning state: [count_small | count_large | cursor_large | counters of this pass] (zeroed at the
-    // start of every pass, padded to 16 bytes) [block_count | block_live | pending_count]
-    const size_t zero_words = (count_words + kCountersPerPass + 3) & ~(size_t)3;
-    SR_HIP(dev->tile_count.ensure((zero_words + 3 * (size_t)vpp * std::max(n_blocks, 1u)) * 4));
-    SR_HIP(dev->survivor_count.ensure((size_t)vpp * std::max(n_blocks, 1u) * bt * 4));
+    // layout of the binning state: [count_small | count_large | cursor_large | pending_total per view | counters of this pass]
+    // (zeroed at the start of every pass, padded to 16 bytes) [block_count: written by the binning kernel]
+    const size_t zero_words = (count_words + vpp + kNumPassCounters + 3) & ~(size_t)3;
+    SR_HIP(dev->tile_count.ensure((zero_words + (size_t)vpp * n_blocks) * 4));
+    SR_HIP(dev->pending.ensure((size_t)vpp * pending_stride * 4));
     SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
-    SR_HIP(dev->survivors.ensure((size_t)vpp * std::max(n_blocks, 1u) * setup_block_records() * sizeof(BinRecord)));
+    SR_HIP(dev->records.ensure((size_t)vpp * n_blocks * setup_block_records() * sizeof(BinRecord)));
     SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
-    const bool near_clip = (dev->variants & kVariantNearClip) != 0;
-    if (near_clip) SR_HIP(dev->clip.ensure(16 + (size_t)dev->clip_capacity * sizeof(uint2)));
-    const bool culling = (dev->variants & kVariantClusterCull) && m->d_clusters && m->d_pos4 && tg->cull_views.size() == n_views;
-    const size_t view_bytes = (size_t)n_views * (sizeof(ViewXform) + (culling ? sizeof(ViewCull) : 0));   // [transforms][cull constants]
+    SR_HIP(dev->clip.ensure((size_t)dev->clip_capacity * sizeof(uint2)));
+    const size_t view_bytes = (size_t)n_views * sizeof(ViewXform);
     SR_HIP(dev->views.ensure(view_bytes));
     sr_device_t::Staging& sg = dev->staging[dev->staging_next++ & 3u];
     if (!sg.ev) SR_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
@@ -362,9 +214,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         dev->events_used = (size_t)passes * kNumStageEvents;
     } else dev->events_used = 0;
 
-    std::memcpy(sg.h, tg->views.data(), (size_t)n_views * sizeof(ViewXform));
-    if (culling) std::memcpy((char*)sg.h + (size_t)n_views * sizeof(ViewXform), tg->cull_views.data(), (size_t)n_views * sizeof(ViewCull));
-    if (culling && dev->d_cull_violations) SR_HIP(hipMemsetAsync(dev->d_cull_violations, 0, 4, st));
+    std::memcpy(sg.h, tg->views.data(), view_bytes);
 
     ScreenPlanes sp{};
     sp.xy = (int2*)dev->screen.ptr;
@@ -374,23 +224,17 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     b.count_small = (uint32_t*)dev->tile_count.ptr;
     b.count_large = b.count_small + (size_t)vpp * n_tiles;
     b.cursor_large = b.count_large + (size_t)vpp * n_tiles;
-    b.counters = b.count_small + count_words;
+    b.pending_total = b.count_small + count_words;
+    b.counters = b.pending_total + vpp;
     b.block_count = b.count_small + zero_words;
-    b.block_live = b.block_count + (size_t)vpp * std::max(n_blocks, 1u);
-    b.pending_count = b.block_live + (size_t)vpp * std::max(n_blocks, 1u);
-    b.pending = (uint32_t*)dev->survivor_count.ptr;
+    b.pending = (uint32_t*)dev->pending.ptr;
+    b.pending_stride = pending_stride;
     b.n_blocks = n_blocks;
-    {   // stride close to the golden ratio of n_blocks and coprime with it
-        auto gcd = [](uint32_t a, uint32_t c) { while (c) { uint32_t t = a % c; a = c; c = t; } return a; };
-        uint32_t stride = (uint32_t)((double)n_blocks * 0.6180339887498949) | 1u;
-        while (n_blocks > 2 && gcd(stride, n_blocks) != 1u) stride += 2u;
-        b.block_stride = n_blocks > 2 ? stride % n_blocks : 1u;
-        if (b.block_stride == 0) b.block_stride = 1u;
-    }
     b.tile_offset = (uint32_t*)dev->tile_offset.ptr;
     b.refs = (uint32_t*)dev->refs.ptr;
     b.ref_capacity = (uint32_t)dev->ref_capacity;
-    b.records = (BinRecord*)dev->survivors.ptr;
+    b.records = (BinRecord*)dev->records.ptr;
+    ClipList clip{(uint2*)dev->clip.ptr, dev->clip_capacity};
 
     const sr_texture_t* albedo = tg->tex[0];
     const sr_texture_t* metallic = tg->tex[2];
@@ -401,58 +245,28 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         const ViewXform* d_views = (const ViewXform*)dev->views.ptr + v0;
         hipEvent_t* ev = dev->profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
         if (ev) SR_HIP(hipEventRecord(ev[0], st));
-        // the dirty map needs the set-up kernel that marks it: meshes created without the packed positions fall back to the full clear
-        const bool fused = (dev->variants & kVariantFusedGeometry) && m->d_pos4;
-        const DirtyMap dirty = fused && tg->dirty.flags ? tg->dirty : DirtyMap{nullptr, 0, 0};
-        if (dirty.flags)
-            launch_begin_pass_dirty(st, tg->d_vis, g, v0, nv, dirty, b.count_small, zero_words * 4,
-                                    sg.d, dev->views.ptr, pass == 0 ? view_bytes : 0);
-        else
-            launch_begin_pass(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples, b.count_small, zero_words * 4,
-                              sg.d, dev->views.ptr, pass == 0 ? view_bytes : 0);
+        launch_begin_pass(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples, b.count_small, zero_words * 4,
+                          sg.d, dev->views.ptr, pass == 0 ? view_bytes : 0);
         if (pass == 0) { SR_HIP(hipEventRecord(sg.ev, st)); sg.in_flight = true; }
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
-        if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
+        launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        const bool sparse = fused && tg->sparse && m->n_tris > 0;
-        ClusterCull cull{nullptr, nullptr, nullptr};
-        if (culling) {
-            cull.clusters = m->d_clusters;
-            cull.views = (const ViewCull*)((const char*)dev->views.ptr + (size_t)n_views * sizeof(ViewXform)) + v0;
-            cull.violations = (dev->variants & kVariantClusterVerify) ? dev->d_cull_violations : nullptr;
-        }
-        ClipList clip{nullptr, nullptr, 0, nullptr};
-        if (near_clip) {
-            clip.state = (uint32_t*)dev->clip.ptr;
-            clip.entries = (uint2*)((char*)dev->clip.ptr + 16);
-            clip.capacity = dev->clip_capacity;
-            clip.count = b.counters + 7;   // zeroed with the other counters at the start of the pass
-            SR_HIP(hipMemsetAsync(clip.state, 0, 16, st));
-        }
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, fused ? m->d_pos4 : nullptr, d_views, dirty, !sparse, cull,
-                     fused ? clip : ClipList{nullptr, nullptr, 0, nullptr});
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, v0, ev ? ev[3] : nullptr);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
-        // (before the scan / sparse-tail kernel, which reports the number of dropped triangles to the host)
-        if (clip.entries) launch_near_clip(st, m->d_idx, m->n_tris, fused ? m->d_pos4 : nullptr, m->px, m->py, m->pz, sp, nv, d_views, g, clip, b, tg->d_vis, v0, dirty, pass_counters);
-        if (sparse) {   // one kernel resolves whatever set-up left pending; its time is reported as the raster stage
-            if (ev) { SR_HIP(hipEventRecord(ev[5], st)); SR_HIP(hipEventRecord(ev[6], st)); }
-            launch_sparse_tail(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty, pass_counters);
-        } else {
-            launch_scan(st, b, nv * n_tiles, nv, pass_counters);
-            if (ev) SR_HIP(hipEventRecord(ev[5], st));
-            launch_fill(st, g, b, m->n_tris, nv);
-            if (ev) SR_HIP(hipEventRecord(ev[6], st));
-            launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dirty, (dev->variants & kVariantRaster512) != 0);
-        }
+        // (before the scan kernel, which reports the counters to the host)
+        launch_near_clip(st, m->d_idx, m->n_tris, m->px, m->py, m->pz, d_views, g, clip, b, tg->d_vis, v0);
+        launch_scan(st, b, nv * n_tiles, nv, pass_counters);
+        if (ev) SR_HIP(hipEventRecord(ev[5], st));
+        launch_fill(st, g, b, m->n_tris, nv);
+        if (ev) SR_HIP(hipEventRecord(ev[6], st));
+        launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dev->raster_half);
         if (ev) SR_HIP(hipEventRecord(ev[7], st));
         FragLaunch f{};
-        f.idx = m->d_idx; f.verts_aos = m->d_aos; f.screen = sp; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
+        f.idx = m->d_idx; f.verts_aos = m->d_aos; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
-        f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv; f.dirty = dirty;
-        f.exact_vertices = (dev->variants & kVariantExactShading) != 0;
-        f.max_anisotropy = (dev->variants & kVariantAnisotropic) ? std::max(albedo->samp.max_anisotropy, 1.0f) : 1.0f;
+        f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv;
         launch_fragment(st, f);
         if (ev) SR_HIP(hipEventRecord(ev[8], st));
     }
@@ -470,11 +284,10 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
     if (!tg->check_pending) return SR_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
         uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0, clipped = 0;
-        const bool near_clip = (dev->variants & kVariantNearClip) != 0;
         for (uint32_t p = 0; p < tg->passes; ++p) {
             const uint32_t* c = tg->h_counters + (size_t)p * kCountersPerPass;
             worst = std::max<uint64_t>(worst, c[0]); total += c[0]; unproj += c[2]; binned += c[3]; micro += c[4];
-            if (near_clip) clipped += c[6];
+            clipped += c[6];
         }
         tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned; tg->micro = micro; tg->clipped = clipped;
         if (worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
@@ -485,6 +298,23 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
         SR_HIP(hipStreamSynchronize(dev->stream));
     }
     return fail(SR_ERR_UNSUPPORTED, "tile reference list exceeds 2^32 entries in one pass");
+}
+
+// A mesh or a texture is about to be destroyed: resolve every draw of this device that still refers to it (a draw
+// whose tile reference list overflowed is re-issued when its target is next read, and needs them) and drop the
+// references.  The reference's buffers and images may be destroyed as soon as the device is idle (src/main.cpp:170,
+// 300-347); this keeps that order legal here.
+void release_references(sr_device_t* dev, const sr_mesh_t* mesh, const sr_texture_t* tex)
+{
+    for (sr_target_t* t : dev->targets) {
+        bool uses = mesh && t->mesh == mesh;
+        for (int k = 0; k < 4 && tex; ++k) uses = uses || t->tex[k] == tex;
+        if (!uses) continue;
+        if (t->check_pending) (void)finish_target(dev, t);
+        t->check_pending = false;   // (if the re-issued draw failed, its counters are what they are)
+        t->mesh = nullptr;
+        for (int k = 0; k < 4; ++k) t->tex[k] = nullptr;
+    }
 }
 
 }  // namespace
@@ -529,22 +359,22 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     SR_HIP(hipSetDevice(hip_ordinal));
     sr_device_t* dev = new sr_device_t();
     dev->ordinal = hip_ordinal;
-    SR_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
     float dec[256], thr[256];
     for (int c = 0; c < 256; ++c) dec[c] = (float)srgb_decode_d(c / 255.0);
     for (int c = 0; c < 255; ++c) thr[c] = (float)srgb_decode_d((c + 0.5) / 255.0);
     thr[255] = 3.0e38f;
-    SR_HIP(hipMalloc((void**)&dev->d_decode, sizeof dec));
-    SR_HIP(hipMalloc((void**)&dev->d_thresh, sizeof thr));
-    SR_HIP(hipMemcpy(dev->d_decode, dec, sizeof dec, hipMemcpyHostToDevice));
-    SR_HIP(hipMemcpy(dev->d_thresh, thr, sizeof thr, hipMemcpyHostToDevice));
-    if (const char* e = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(e);
-    if (const char* e = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 30;
-    if (const char* e = std::getenv("SR_REF_CAPACITY")) dev->ref_capacity = (uint64_t)std::max(1, std::atoi(e));   // initial size of the tile reference list (tests: force the grow-and-redraw path)
-    if (const char* e = std::getenv("SR_CLIP_CAPACITY")) dev->clip_capacity = (uint32_t)std::max(1, std::atoi(e));   // tests: a full clip list
-    if (const char* e = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(e)) << 20;   // small budgets: many passes per draw
-    dev->variants = parse_variants(std::getenv("SR_VARIANT"));
-    if (dev->variants & kVariantClusterVerify) SR_HIP(hipMalloc((void**)&dev->d_cull_violations, 4));
+    hipError_t e = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->d_decode, sizeof dec);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->d_thresh, sizeof thr);
+    if (e == hipSuccess) e = hipMemcpy(dev->d_decode, dec, sizeof dec, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dev->d_thresh, thr, sizeof thr, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)sr_device_destroy(dev); SR_HIP(e); }
+    if (const char* v = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(v);
+    if (const char* v = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 30;
+    if (const char* v = std::getenv("SR_REF_CAPACITY")) dev->ref_capacity = (uint64_t)std::max(1, std::atoi(v));   // initial size of the tile reference list (tests: force the grow-and-redraw path)
+    if (const char* v = std::getenv("SR_CLIP_CAPACITY")) dev->clip_capacity = (uint32_t)std::max(1, std::atoi(v));   // tests: a full clip list
+    if (const char* v = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 20;   // small budgets: many passes per draw
+    if (const char* v = std::getenv("SR_RASTER_HALF")) dev->raster_half = std::atoi(v) != 0;
     *out = dev;
     return SR_OK;
 }
@@ -553,13 +383,14 @@ int sr_device_destroy(sr_device dev)
 {
     if (!dev) return SR_OK;
     (void)hipSetDevice(dev->ordinal);
-    (void)hipStreamSynchronize(dev->stream);
+    if (dev->stream) (void)hipStreamSynchronize(dev->stream);
     for (hipEvent_t e : dev->events) (void)hipEventDestroy(e);
-    dev->screen.release(); dev->tile_count.release(); dev->tile_offset.release(); dev->survivors.release();
-    dev->survivor_count.release(); dev->refs.release(); dev->views.release(); dev->counters.release(); dev->clip.release();
+    dev->screen.release(); dev->tile_count.release(); dev->tile_offset.release(); dev->records.release();
+    dev->pending.release(); dev->refs.release(); dev->views.release(); dev->clip.release();
     for (auto& sg : dev->staging) { if (sg.h) (void)hipHostFree(sg.h); if (sg.ev) (void)hipEventDestroy(sg.ev); }
-    (void)hipFree(dev->d_decode); (void)hipFree(dev->d_thresh); (void)hipFree(dev->d_cull_violations);
-    (void)hipStreamDestroy(dev->stream);
+    (void)hipFree(dev->d_decode); (void)hipFree(dev->d_thresh);
+    if (dev->stream) (void)hipStreamDestroy(dev->stream);
+    for (sr_target_t* t : dev->targets) { t->mesh = nullptr; t->check_pending = false; }   // targets outliving their device can only be destroyed
     delete dev;
     return SR_OK;
 }
@@ -588,21 +419,11 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
     hipError_t e = hipMalloc(&m->d_aos, nv * 32);
     if (e == hipSuccess) e = hipMalloc((void**)&m->px, nv * 12);
     if (e == hipSuccess) e = hipMalloc((void**)&m->d_idx, ni * 4);
-    if (e == hipSuccess && (dev->variants & kVariantFusedGeometry)) e = hipMalloc(&m->d_pos4, nv * 16);
-    if (e != hipSuccess) { (void)hipFree(m->d_aos); (void)hipFree(m->px); (void)hipFree(m->d_idx); (void)hipFree(m->d_pos4); delete m; SR_HIP(e); }
+    if (e != hipSuccess) { (void)hipFree(m->d_aos); (void)hipFree(m->px); (void)hipFree(m->d_idx); delete m; SR_HIP(e); }
     m->py = m->px + nv; m->pz = m->py + nv;
     if (n_vertices) e = hipMemcpyAsync(m->d_aos, vertices, (size_t)n_vertices * 32, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess && n_tris) e = hipMemcpyAsync(m->d_idx, indices, (size_t)n_tris * 12, hipMemcpyHostToDevice, dev->stream);
-    if (e == hipSuccess) {
-        launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
-        if (m->d_pos4) launch_pack_positions(dev->stream, m->d_aos, n_vertices, m->d_pos4);
-    }
-    if (e == hipSuccess && (dev->variants & kVariantClusterCull) && n_tris) {
-        const std::vector<ClusterRec> recs = build_clusters((const float*)vertices, indices, n_tris);
-        m->n_clusters = (uint32_t)recs.size();
-        e = hipMalloc((void**)&m->d_clusters, recs.size() * sizeof(ClusterRec));
-        if (e == hipSuccess) e = hipMemcpy(m->d_clusters, recs.data(), recs.size() * sizeof(ClusterRec), hipMemcpyHostToDevice);
-    }
+    if (e == hipSuccess) launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);   // uploaded on return, like the reference's blocking staging copy
     if (e != hipSuccess) { (void)sr_mesh_destroy(dev, m); SR_HIP(e); }
@@ -613,8 +434,12 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
 int sr_mesh_destroy(sr_device dev, sr_mesh mesh)
 {
     if (!mesh) return SR_OK;
-    if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
-    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx); (void)hipFree(mesh->d_pos4); (void)hipFree(mesh->d_clusters);
+    if (dev) {
+        (void)hipSetDevice(dev->ordinal);
+        release_references(dev, mesh, nullptr);
+        (void)hipStreamSynchronize(dev->stream);
+    }
+    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx);
     delete mesh;
     return SR_OK;
 }
@@ -630,7 +455,7 @@ int sr_texture_create_rgba8_srgb(sr_device dev, const void* rgba8, int width, in
 {
     if (!dev || !out || !rgba8) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
-    if (width <= 0 || height <= 0 || width > 32768 || height > 32768) return fail(SR_ERR_INVALID_ARGUMENT, "texture size out of range");
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384) return fail(SR_ERR_INVALID_ARGUMENT, "texture size out of range (1..16384)");
     SR_HIP(hipSetDevice(dev->ordinal));
     sr_texture_t* t = new sr_texture_t();
     t->w = width; t->h = height;
@@ -657,7 +482,11 @@ int sr_texture_create_rgba8_srgb(sr_device dev, const void* rgba8, int width, in
 int sr_texture_destroy(sr_device dev, sr_texture tex)
 {
     if (!tex) return SR_OK;
-    if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
+    if (dev) {
+        (void)hipSetDevice(dev->ordinal);
+        release_references(dev, nullptr, tex);
+        (void)hipStreamSynchronize(dev->stream);
+    }
     (void)hipFree(tex->d_chain);
     delete tex;
     return SR_OK;
@@ -793,19 +622,12 @@ int sr_target_create(sr_device dev, int width, int height, int samples, uint32_t
     if (e == hipSuccess) e = hipMalloc((void**)&t->d_color_own, px * 4 * n_views);
     if (e != hipSuccess) { (void)hipFree(t->d_vis); delete t; SR_HIP(e); }
     t->d_color = t->d_color_own;
-    if (dev->variants & kVariantDirtyBlocks) {
-        // the map's invariant -- an unmarked block holds only the clear value -- starts with one full clear
-        t->dirty.nbx = (g.rw + (1 << kDirtyLog2W) - 1) >> kDirtyLog2W;
-        t->dirty.nby = (g.rh + (1 << kDirtyLog2H) - 1) >> kDirtyLog2H;
-        const size_t flag_bytes = (size_t)n_views * t->dirty.nbx * t->dirty.nby * 4;
-        e = hipMalloc((void**)&t->dirty.flags, flag_bytes);
-        if (e == hipSuccess) e = hipMemsetAsync(t->dirty.flags, 0, flag_bytes, dev->stream);
-        if (e == hipSuccess) {
-            launch_begin_pass(dev->stream, t->d_vis, px * samples * n_views, nullptr, 0, nullptr, nullptr, 0);
-            e = hipStreamSynchronize(dev->stream);
-        }
-        if (e != hipSuccess) { (void)hipFree(t->d_vis); (void)hipFree(t->d_color_own); (void)hipFree(t->dirty.flags); delete t; SR_HIP(e); }
-    }
+    // room for the counters of a one-pass draw, so that such a draw allocates nothing here
+    e = hipHostMalloc((void**)&t->h_counters, (size_t)kCountersPerPass * 4, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&t->hd_counters, t->h_counters, 0);
+    if (e != hipSuccess) { (void)hipFree(t->d_vis); (void)hipFree(t->d_color_own); if (t->h_counters) (void)hipHostFree(t->h_counters); delete t; SR_HIP(e); }
+    t->h_counters_cap = 1;
+    dev->targets.push_back(t);
     *out = t;
     return SR_OK;
 }
@@ -813,8 +635,11 @@ int sr_target_create(sr_device dev, int width, int height, int samples, uint32_t
 int sr_target_destroy(sr_device dev, sr_target target)
 {
     if (!target) return SR_OK;
-    if (dev) { (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream); }
-    (void)hipFree(target->d_vis); (void)hipFree(target->d_color_own); (void)hipFree(target->dirty.flags);
+    if (dev) {
+        (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream);
+        dev->targets.erase(std::remove(dev->targets.begin(), dev->targets.end(), target), dev->targets.end());
+    }
+    (void)hipFree(target->d_vis); (void)hipFree(target->d_color_own);
     if (target->h_counters) (void)hipHostFree(target->h_counters);
     delete target;
     return SR_OK;
@@ -882,20 +707,7 @@ int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_block
             }
     }
     (void)hipGetLastError();
-    if (dev->variants & kVariantSparseTail) {
-        // Decide from the counters of this target's previous draw (pinned memory the kernels write; it may still be
-        // in flight, in which case the figures are one frame older -- either way only speed depends on them).
-        bool next = (dev->variants & kVariantSparseTailForce) != 0;
-        if (!next && target->passes > 0 && target->mesh == mesh) {
-            next = true;
-            for (uint32_t p = 0; p < target->passes; ++p) {
-                const uint32_t* c = target->h_counters + (size_t)p * kCountersPerPass;
-                if (c[3] > kSparseMaxPending || (target->sparse ? c[5] > kSparseMaxSteps : c[0] > kSparseMaxRefs)) next = false;
-            }
-        }
-        target->sparse = next;
-    }
-    target->mesh = mesh;
+    target->mesh = mesh; target->mesh_verts = mesh->n_verts; target->mesh_tris = mesh->n_tris;
     for (int k = 0; k < 4; ++k) target->tex[k] = textures[k];
     target->views.resize(n_views);
     for (uint32_t v = 0; v < n_views; ++v) {
@@ -905,11 +717,8 @@ int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_block
         mat4_mul_mat4_host(u + 32, u + 16, x.pv);   // proj * view
         std::memcpy(x.cam, u + 48, 12);
         static const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-        x.model_is_identity = std::memcmp(x.model, identity, 64) == 0 ? 1.0f : 0.0f;   // lets the variants' kernels skip the product with it
+        x.model_is_identity = std::memcmp(x.model, identity, 64) == 0 ? 1.0f : 0.0f;
     }
-    target->cull_views.clear();
-    if (dev->variants & kVariantClusterCull)
-        for (uint32_t v = 0; v < n_views; ++v) target->cull_views.push_back(make_view_cull(target->views[v]));
     target->drawn = true;
     return issue_draw(dev, target);
 }
@@ -923,23 +732,22 @@ int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)
     int rc = finish_target(dev, target);
     if (rc != SR_OK) return rc;
     const FrameGeom& g = target->g;
-    const sr_mesh_t* m = target->mesh;
-    const uint32_t n_views = (uint32_t)target->views.size();
+    const uint32_t n_views = (uint32_t)target->views.size(), mesh_tris = target->mesh_tris;
     std::memset(out, 0, sizeof *out);
-    out->vertices = (uint64_t)m->n_verts * n_views;
-    out->triangles = (uint64_t)m->n_tris * n_views;
+    out->vertices = (uint64_t)target->mesh_verts * n_views;
+    out->triangles = (uint64_t)mesh_tris * n_views;
     out->tile_refs = target->total_refs;
     out->triangles_unprojectable = target->unprojectable;
     out->pixels = (uint64_t)g.rw * g.rh * n_views;
     uint32_t* flags = nullptr; uint64_t* sums = nullptr;
-    SR_HIP(hipMalloc((void**)&flags, (size_t)std::max<uint32_t>(m->n_tris, 1) * 4));
+    SR_HIP(hipMalloc((void**)&flags, (size_t)std::max<uint32_t>(mesh_tris, 1) * 4));
     hipError_t e = hipMalloc((void**)&sums, 16);
     if (e != hipSuccess) { (void)hipFree(flags); SR_HIP(e); }
     e = hipMemsetAsync(sums, 0, 16, dev->stream);
     const size_t px = (size_t)g.rw * g.rh;
     for (uint32_t v = 0; v < n_views && e == hipSuccess; ++v) {
-        e = hipMemsetAsync(flags, 0, (size_t)std::max<uint32_t>(m->n_tris, 1) * 4, dev->stream);
-        launch_stats(dev->stream, target->d_vis + px * g.samples * v, px, g.samples, flags, m->n_tris, sums, sums + 1);
+        e = hipMemsetAsync(flags, 0, (size_t)std::max<uint32_t>(mesh_tris, 1) * 4, dev->stream);
+        launch_stats(dev->stream, target->d_vis + px * g.samples * v, px, g.samples, flags, mesh_tris, sums, sums + 1);
     }
     uint64_t h[2] = {0, 0};
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
@@ -951,27 +759,6 @@ int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)
     out->triangles_binned = target->binned;
     out->triangles_direct = target->micro;
     out->triangles_clipped = target->clipped;
-    if ((dev->variants & kVariantClusterCull) && m->d_clusters && target->cull_views.size() == n_views) {
-        // re-evaluate the cluster test for the draw's views (its device copy may have been overwritten by a later draw)
-        ViewCull* d_cv = nullptr; uint64_t* d_total = nullptr; uint64_t total = 0;
-        hipError_t ce = hipMalloc((void**)&d_cv, (size_t)n_views * sizeof(ViewCull));
-        if (ce == hipSuccess) ce = hipMalloc((void**)&d_total, 8);
-        if (ce == hipSuccess) ce = hipMemcpy(d_cv, target->cull_views.data(), (size_t)n_views * sizeof(ViewCull), hipMemcpyHostToDevice);
-        if (ce == hipSuccess) ce = hipMemsetAsync(d_total, 0, 8, dev->stream);
-        if (ce == hipSuccess) {
-            launch_count_culled_clusters(dev->stream, ClusterCull{m->d_clusters, d_cv, nullptr}, g, m->n_clusters, n_views, d_total);
-            ce = hipStreamSynchronize(dev->stream);
-        }
-        if (ce == hipSuccess) ce = hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost);
-        (void)hipFree(d_cv); (void)hipFree(d_total);
-        SR_HIP(ce);
-        out->clusters_culled = total;
-        if (dev->d_cull_violations) {   // of the most recent draw on this device
-            uint32_t v = 0;
-            SR_HIP(hipMemcpy(&v, dev->d_cull_violations, 4, hipMemcpyDeviceToHost));
-            out->cull_violations = v;
-        }
-    }
     return SR_OK;
 }
 

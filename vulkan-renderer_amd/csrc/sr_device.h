@@ -61,6 +61,7 @@ struct TexDesc {
     const uint32_t* texels;  // RGBA8, all levels back to back
     int w, h, levels;
     float min_lod, max_lod, bias;
+    float max_aniso;         // the sampler's maxAnisotropy (src/texture.cpp:255-256); <= 1: isotropic footprint
     uint32_t level_off[kMaxMipLevels];  // in texels
 };
 
@@ -200,138 +201,48 @@ struct BinRecord {            // 12 bytes, written by set-up, read by fill
 constexpr uint32_t kLargeTri = 0xFFFFFFFFu;
 constexpr uint32_t kMaxSmallTiles = 4;   // a "small" triangle overlaps at most 2x2 tiles and gets one record per tile
 
+// counters of one pass (all its views summed), zeroed by the begin kernel
+enum : uint32_t {
+    kCtrRefs = 0,          // total tile references (written by the scan kernel)
+    kCtrRefsDropped = 1,   // references that found no room in the list
+    kCtrUnprojectable = 2, // triangles that would need clipping and could not be clipped (clip list full, degenerate projection)
+    kCtrMicro = 4,         // micro-triangles resolved by the set-up kernel itself
+    kCtrClipListed = 7,    // triangles put on the clip list by set-up (may exceed its capacity)
+    kCtrClipped = 8,       // triangles the near-plane clipper cut and drew
+    kNumPassCounters = 16,
+};
+
 struct BinBuffers {
-    // per (view, tile) counters, cleared before set-up: [3][views*tiles]
-    uint32_t* count_small;    // references of small triangles (positions handed out by set-up)
+    // per (view, tile) counters, zeroed at the start of a pass: [3][views*tiles]
+    uint32_t* count_small;    // references of small triangles (positions handed out by the binning kernel)
     uint32_t* count_large;    // references of large triangles (appended after the small ones by fill)
     uint32_t* cursor_large;   // fill-pass cursor of the large part
     uint32_t* tile_offset;    // [views*tiles + 1]: exclusive scan of count_small + count_large
     uint32_t* refs;           // [capacity]: triangle ids grouped by (view, tile)
     uint32_t ref_capacity;
-    uint32_t* pending;        // [views][blocks][block triangles]: ids of the triangles set-up hands to the binning kernel
-    uint32_t* pending_count;  // [views][blocks]
-    BinRecord* records;       // [views][blocks][block triangles * kMaxSmallTiles]; each set-up block owns one segment
-    uint32_t* block_count;    // [views][blocks]: records written by each set-up block
-    uint32_t* block_live;     // [views][blocks]: pending triangles | micro-triangles resolved << 16, per set-up block
-    uint32_t block_stride;    // coprime with n_blocks: hardware block i works on triangle block (i * block_stride) % n_blocks, so that
-                              // blocks running at the same time touch different tiles (their per-tile atomics do not pile up)
-    uint32_t n_blocks;        // set-up blocks per view
-    uint32_t* counters;       // [8]: total refs, dropped refs, unprojectable triangles, binned triangles, micro-triangles resolved directly
+    uint32_t* pending;        // [views][pending_stride]: ids of the triangles set-up hands to the binning kernel, one list per view;
+                              // a set-up block reserves its place with one atomic add on pending_total
+    uint32_t* pending_total;  // [views], zeroed at the start of a pass
+    uint32_t pending_stride;  // >= triangles of the mesh
+    BinRecord* records;       // [views][chunks][chunk triangles * kMaxSmallTiles]: the binning kernel takes the pending list in chunks,
+                              // each chunk owns one segment
+    uint32_t* block_count;    // [views][chunks]: records written for each chunk
+    uint32_t n_blocks;        // chunks per view at most (= set-up blocks per view)
+    uint32_t* counters;       // [kNumPassCounters]
 };
 
-// Dirty map (pipeline variant "dirty_blocks"): one flag per 32x8-pixel block of every view of a target,
-// set by whatever writes a sample of the block into the visibility buffer.  Blocks whose flag is clear
-// hold nothing but the clear value, so the shading pass need not read them and the next draw need not
-// clear them: the start of a draw clears the marked blocks of the views it draws and takes their flags back.
-constexpr int kDirtyLog2W = 5, kDirtyLog2H = 3;   // 32 x 8 pixels: the shading pass's workgroup shape
-struct DirtyMap {
-    uint32_t* flags;   // [views of the target][nby][nbx]; null when the variant is off
-    int nbx, nby;
-};
-// lx, ly: pixel position relative to the stored rectangle; view: index inside the target
-__device__ inline void mark_dirty(const DirtyMap& d, uint32_t view, int lx, int ly)
-{
-    d.flags[((size_t)view * d.nby + (ly >> kDirtyLog2H)) * d.nbx + (lx >> kDirtyLog2W)] = 1u;
-}
-
-// Cluster culling (pipeline variant "cluster_cull").  A cluster is 64 consecutive triangles of the index
-// list: what one wave of a set-up workgroup handles in one of its four turns, so the decision is the
-// same for every lane of a wave.  At mesh creation each cluster gets a
-// bounding sphere, a cone that contains the unit normals of its triangles, its smallest inradius and
-// its smallest perimeter; at draw time a cluster is skipped before any per-triangle work when the test
-// below PROVES that the per-triangle path would draw nothing from it:
-//   * every point of the sphere is in front of the eye plane and inside the guard band (so no triangle
-//     can be "unprojectable", which is counted), and
-//   * either the sphere's window-space bounds miss the stored rectangle by a pixel or more, or every
-//     triangle is back-facing by a margin that exceeds the largest change snapping and float rounding
-//     can make to its window-space area.
-// Facing in window space follows from object space: with clip = P (p - e) for the 3x3 matrix P made
-// of rows x, y, w of proj*view*model and e the centre of projection, the doubled window-space area is
-//   area2 = -(W H / 4) det(P) ((p0 - e) . N) / (w0 w1 w2),  N = (p1 - p0) x (p2 - p0),
-// and a triangle is drawn only if area2 < 0.
-constexpr uint32_t kClusterTris = 64;
-struct ClusterRec {            // 48 bytes
-    float cx, cy, cz, r;       // bounding sphere, object space
-    float ax, ay, az;          // cone axis (unit)
-    float cos_alpha;           // every triangle normal n has n . axis >= cos_alpha; <= 0: no usable cone
-    float sin_alpha;
-    float rho_min;             // smallest 2*area/perimeter (inradius) of the cluster's triangles, object space
-    float p_min;               // smallest perimeter
-    float pad;
-};
-struct ViewCull {              // 96 bytes, per view, computed on the host in double precision
-    float R0[3], t0;           // rows x, y, w of proj*view*model
-    float R1[3], t1;
-    float R3[3], t3;
-    float e[3];                // centre of projection in object space
-    float sigma;               // sign of det(P)
-    float absdet;              // |det(P)|
-    float nR0, nR1, nR3;       // lengths of the rows' 3-vectors
-    float cone_ok;             // 0: no finite centre of projection (or a degenerate matrix): sphere test only
-    float pad[3];
-};
-struct ClusterCull {
-    const ClusterRec* clusters;   // null: variant off
-    const ViewCull* views;        // views of the pass
-    uint32_t* violations;         // non-null: verification mode -- do not skip, count the triangles of would-be-skipped
-                                  // clusters that the per-triangle path draws or counts (must stay 0)
-};
-
-__device__ inline bool cluster_is_invisible(const ClusterRec& cl, const ViewCull& vc, const FrameGeom& g)
-{
-    const float xc = fmaf(vc.R0[2], cl.cz, fmaf(vc.R0[1], cl.cy, vc.R0[0] * cl.cx)) + vc.t0;
-    const float yc = fmaf(vc.R1[2], cl.cz, fmaf(vc.R1[1], cl.cy, vc.R1[0] * cl.cx)) + vc.t1;
-    const float wc = fmaf(vc.R3[2], cl.cz, fmaf(vc.R3[1], cl.cy, vc.R3[0] * cl.cx)) + vc.t3;
-    const float r = cl.r * 1.0001f;   // slack for the rounding of the three sums above
-    const float dw = r * vc.nR3, dx = r * vc.nR0, dy = r * vc.nR1;
-    const float wmin = wc - dw, wmax = wc + dw;
-    if (!(wmin > 1.0e-4f * wmax)) return false;                      // touches the eye plane (or NaN)
-    const float rmin = 1.0f / wmin, rmax = 1.0f / wmax;
-    const float x_hi = xc + dx, x_lo = xc - dx, y_hi = yc + dy, y_lo = yc - dy;
-    const float umax = fmaxf(x_hi * rmin, x_hi * rmax), umin = fminf(x_lo * rmin, x_lo * rmax);   // NDC bounds of the sphere's box
-    const float vmax = fmaxf(y_hi * rmin, y_hi * rmax), vmin = fminf(y_lo * rmin, y_lo * rmax);
-    const float hw = 0.5f * (float)g.W, hh = 0.5f * (float)g.H;
-    const float U = fmaxf(fabsf(umax), fabsf(umin)), V = fmaxf(fabsf(vmax), fabsf(vmin));
-    if (!(U * hw + hw < 0.5f * kGuardPx && V * hh + hh < 0.5f * kGuardPx)) return false;   // a vertex could leave the guard band
-    // window-space bounds, one pixel of slack (snapping moves a vertex by 1/512 pixel, rounding by far less)
-    const float px_lo = umin * hw + hw - 1.0f, px_hi = umax * hw + hw + 1.0f;
-    const float py_lo = -vmax * hh + hh - 1.0f, py_hi = -vmin * hh + hh + 1.0f;
-    if (px_hi < (float)g.rx || px_lo > (float)(g.rx + g.rw) || py_hi < (float)g.ry || py_lo > (float)(g.ry + g.rh)) return true;
-    // back-face cone
-    if (!(cl.cos_alpha > 0.0f) || vc.cone_ok == 0.0f || !(U <= 4.0f && V <= 4.0f)) return false;
-    const float ex = cl.cx - vc.e[0], ey = cl.cy - vc.e[1], ez = cl.cz - vc.e[2];
-    const float D = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
-    if (!(D > 2.0f * r)) return false;
-    const float cosg = fminf(fmaxf(vc.sigma * fmaf(ez, cl.az, fmaf(ey, cl.ay, ex * cl.ax)) / D, -1.0f), 1.0f);
-    const float sing = sqrtf(fmaxf(1.0f - cosg * cosg, 0.0f));
-    const float cosdiff = cosg * cl.cos_alpha + sing * cl.sin_alpha;        // cos(angle(d, axis) - alpha)
-    const float gmin = -(D * cosdiff + r) * 0.999f;                          // every triangle: -(p0 - e) . n >= gmin
-    if (!(gmin > 0.0f)) return false;
-    // |area2| in pixels^2 >= K * gmin * (2 * area_object); it must exceed the error bound
-    // 2*sqrt(2)*delta*perimeter_pixels + 8*delta^2 with delta = snapping + rounding of a window coordinate
-    const float K = hw * hh * vc.absdet * (rmax * rmax * rmax);
-    const float Lx = hw * (vc.nR0 + U * vc.nR3) * rmin, Ly = hh * (vc.nR1 + V * vc.nR3) * rmin;   // pixels per object-space unit, at most
-    const float L = sqrtf(Lx * Lx + Ly * Ly);
-    const float delta = 1.0f / 512.0f + fmaxf((float)g.W, (float)g.H) * (1.0f / 1048576.0f);
-    const float need = 2.0f * (2.8284272f * delta * L + 8.0f * delta * delta / cl.p_min);    // safety factor 2
-    return K * gmin * cl.rho_min >= need;
-}
-
-// Near-plane clipping (pipeline variant "near_clip").  By default a triangle with one or two vertices that cannot
-// be projected (w <= 0, or outside the guard band) is dropped and counted.  The fixed-function clipper of the
-// reference's pipeline keeps the part of such a triangle inside 0 <= z_c <= w_c (src/main.cpp:559-600 leaves depth
-// clipping on); with the variant on, these triangles are listed (by the fused set-up kernel, or by clip_scan_kernel
-// after the plain one) and near_clip_kernel clips each of them in clip space against the near plane and four side
+// Near-plane clipping.  A triangle with one or two vertices that cannot be projected (w <= 0, or outside the guard
+// band) cannot be rasterised from window coordinates.  The fixed-function clipper of the reference's pipeline keeps the
+// part of such a triangle inside 0 <= z_c <= w_c (src/main.cpp:586 leaves depth clipping on), so the set-up kernel puts
+// these triangles on a list and near_clip_kernel clips each of them in clip space against the near plane and four side
 // planes inside the guard band (near_clip_polygon below) and resolves the convex polygon that is left, as a fan, into
 // the visibility buffer under the id of the triangle it came from -- with the edge functions, depth expression and
 // 64-bit min of every other path.
 // The shading pass recognises such a triangle by its unprojectable vertex and interpolates from clip-space
 // coordinates (shade_pixel).
 struct ClipList {
-    uint2* entries;            // (view inside the pass, triangle); null: variant off
-    uint32_t* count;           // entries appended by set-up (may exceed capacity: the excess is counted as dropped)
-    uint32_t capacity;
-    uint32_t* state;           // [1] triangles clipped, [2] workgroups of near_clip_kernel that have finished (zeroed by the caller)
+    uint2* entries;            // (view inside the pass, triangle)
+    uint32_t capacity;         // entries beyond it are dropped and counted as unprojectable
 };
 
 // window-space record of a clip-space position produced by the clipper: the divide, viewport transform, guard band
@@ -354,24 +265,6 @@ __device__ inline ScreenVertex project_clip_coords(const float* clip, int W, int
     sv.z = zd;
     sv.rw = rw;
     return sv;
-}
-
-// model * (p, 1) with a shortcut for the identity: the general product returns p + 0 then, bit for bit for finite
-// positions, at a third of the cost of a vertex projection.  Used by the geometry kernels of the pipeline variants,
-// which project every vertex once per triangle corner.  (The shading kernels keep the general product: the branch
-// costs them eight registers and a wave of occupancy.)
-__device__ inline void world_position(const ViewXform& vx, float px, float py, float pz, float* wp)
-{
-    if (vx.model_is_identity != 0.0f) { wp[0] = px + 0.0f; wp[1] = py + 0.0f; wp[2] = pz + 0.0f; wp[3] = 1.0f; }
-    else mat4_mul_vec4(vx.model, px, py, pz, 1.0f, wp);
-}
-// project_vertex with that shortcut: the same clip coordinates and window-space record
-__device__ inline ScreenVertex project_vertex_short(const ViewXform& vx, float px, float py, float pz, int W, int H, float* clip)
-{
-    float wp[4];
-    world_position(vx, px, py, pz, wp);
-    mat4_mul_vec4(vx.pv, wp[0], wp[1], wp[2], 1.0f, clip);
-    return project_clip_coords(clip, W, H);
 }
 
 // The clipper proper.  The triangle is clipped in clip space against the near plane (z >= 0) and then against four

@@ -20,15 +20,6 @@ __global__ __launch_bounds__(256) void split_positions_kernel(const float4* __re
     px[i] = a.x; py[i] = a.y; pz[i] = a.z;
 }
 
-// packed 16-byte positions (x, y, z, 1) for the set-up variant that transforms vertices itself
-__global__ __launch_bounds__(256) void pack_positions_kernel(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ pos4)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float4 a = aos[2 * (size_t)i];
-    pos4[i] = make_float4(a.x, a.y, a.z, 1.0f);
-}
-
 // =================================================================================================
 // stage 0: start of a pass.  Clears the visibility buffer (depth 1.0, no triangle; 16 bytes per lane,
 // grid-stride), zeroes the binning counters, and on the first pass of a draw pulls the per-view
@@ -46,35 +37,6 @@ __global__ __launch_bounds__(256) void begin_pass_kernel(ulonglong2* __restrict_
     for (size_t i = gtid; i < n_zero4; i += gstride) zero4[i] = make_uint4(0u, 0u, 0u, 0u);
     const ulonglong2 c = make_ulonglong2(kVisClear, kVisClear);
     for (size_t i = gtid; i < n2; i += gstride) vis2[i] = c;
-}
-
-// Start of a pass with a dirty map: instead of clearing the whole visibility buffer, clear only the
-// 32x8-pixel blocks that were written into since they were last cleared, and take their flags back.
-// One workgroup clears one block per turn: 256 lanes = 32 x 8 pixels, rows of 256 contiguous bytes at
-// one sample per pixel.  vis: the target's whole buffer; views [view0, view0 + n_views) are handled.
-__global__ __launch_bounds__(256) void begin_pass_dirty_kernel(unsigned long long* __restrict__ vis, int rw, int rh, int S, uint32_t view0, uint32_t n_views,
-                                                               DirtyMap dirty, uint4* __restrict__ zero4, size_t n_zero4,
-                                                               const uint4* __restrict__ views_src, uint4* __restrict__ views_dst, uint32_t n_views4)
-{
-    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x, gstride = (size_t)gridDim.x * 256u;
-    if (blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < n_views4; i += 256u) views_dst[i] = views_src[i];
-    for (size_t i = gtid; i < n_zero4; i += gstride) zero4[i] = make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t per_view = (uint32_t)(dirty.nbx * dirty.nby), n_blocks = per_view * n_views;
-    uint32_t* flags = dirty.flags + (size_t)view0 * per_view;
-    const int px = (int)(threadIdx.x & 31u), py = (int)(threadIdx.x >> 5);
-    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const uint32_t was = flags[blk];
-        __syncthreads();             // every lane has read the flag before one of them takes it back
-        if (was == 0u) continue;     // uniform over the workgroup
-        if (threadIdx.x == 0) flags[blk] = 0u;
-        const uint32_t view = view0 + blk / per_view, r = blk % per_view;
-        const int x = (int)(r % (uint32_t)dirty.nbx) * 32 + px, y = (int)(r / (uint32_t)dirty.nbx) * 8 + py;
-        if (x < rw && y < rh) {
-            unsigned long long* cell = vis + (((size_t)view * rh + y) * rw + x) * S;
-            for (int s = 0; s < S; ++s) cell[s] = kVisClear;
-        }
-    }
 }
 
 // =================================================================================================
@@ -208,35 +170,130 @@ __device__ inline void micro_resolve(const MicroEdges& e, uint32_t cov, int x0, 
 
 // Set-up: one lane handles kTrisPerThread triangles (all index loads first, then all vertex loads, so
 // a dozen independent gathers are in flight per lane).  Back faces, degenerate triangles and boxes
-// that contain no sample point are dropped; micro-triangles are resolved on the spot; whatever is
-// left is handed to the binning kernel through the block's own slice of the `pending` list (no
-// atomics: ballots and prefix counts).
+// that contain no sample point are dropped; micro-triangles are resolved on the spot; triangles with
+// one or two vertices that cannot be projected go on the clip list; whatever is left is handed to the
+// binning kernel through the view's pending list (ballots and prefix counts inside the block, one
+// atomic add per block that has any).
 template <int S>
 __global__ __launch_bounds__(256) void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
-                                                    FrameGeom g, BinBuffers b, unsigned long long* __restrict__ vis, uint32_t view0)
+                                                    FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, uint32_t view0)
 {
-#define SR_SETUP_FUSED 0
-#include "sr_setup_body.inc"
-#undef SR_SETUP_FUSED
+    __shared__ uint32_t s_wave[kTrisPerThread * 4];
+    __shared__ uint32_t s_micro[4];
+    __shared__ uint32_t s_base;
+    const uint32_t view = blockIdx.y;
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const uint32_t blk = blockIdx.x;
+    const int2* xy = sp.xy + (size_t)view * sp.n_verts;
+    uint32_t tri[kTrisPerThread], i0[kTrisPerThread], i1[kTrisPerThread], i2[kTrisPerThread];
+    bool in_range[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        tri[k] = blk * kBlockTris + k * 256u + tid;
+        in_range[k] = tri[k] < n_tris;
+        const uint32_t tt = in_range[k] ? tri[k] : 0u;
+        i0[k] = idx[3 * (size_t)tt]; i1[k] = idx[3 * (size_t)tt + 1]; i2[k] = idx[3 * (size_t)tt + 2];
+    }
+    int2 r0[kTrisPerThread], r1[kTrisPerThread], r2[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) { r0[k] = xy[i0[k]]; r1[k] = xy[i1[k]]; r2[k] = xy[i2[k]]; }
+
+    uint32_t n_unproj = 0, n_micro = 0;
+    uint32_t micro_cov[kTrisPerThread], micro_box[kTrisPerThread];   // coverage bits; x0 | y0<<14 | npx<<28
+    bool pend[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        micro_cov[k] = 0; micro_box[k] = 0; pend[k] = false;
+        const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
+        // (differences in unsigned arithmetic: x is INT32_MIN for a vertex that cannot be projected -- the area is not used then, but
+        // the subtraction must not overflow a signed int)
+        const int64_t area2 = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
+                              (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y);
+        if (in_range[k] && bad > 0 && bad < 3) {
+            // needs the near-plane clipper; a full list drops and counts the triangle
+            const uint32_t slot = atomicAdd(&b.counters[kCtrClipListed], 1u);
+            if (slot < clip.capacity) clip.entries[slot] = make_uint2(view, tri[k]);
+            else ++n_unproj;
+        }
+        if (in_range[k] && bad == 0 && area2 < 0) {
+            const int mnx = min(r0[k].x, min(r1[k].x, r2[k].x)), mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
+            const int mny = min(r0[k].y, min(r1[k].y, r2[k].y)), mxy = max(r0[k].y, max(r1[k].y, r2[k].y));
+            int x0, x1, y0, y1;
+            pixel_span<S>(mnx, mxx, x0, x1);
+            pixel_span<S>(mny, mxy, y0, y1);
+            x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+            y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+            const int npx = x1 - x0 + 1, npy = y1 - y0 + 1;
+            if (npx > 0 && npy > 0) {
+                if (npx * npy <= kMicroPixels && mxx - mnx < 16384 && mxy - mny < 16384) {
+                    micro_cov[k] = micro_coverage<S>(micro_edges(r0[k], r1[k], r2[k]), x0, y0, npx, npy);
+                    micro_box[k] = (uint32_t)x0 | ((uint32_t)y0 << 14) | ((uint32_t)npx << 28);
+                    if (micro_cov[k]) ++n_micro;
+                } else pend[k] = true;
+            }
+        }
+    }
+    // micro-triangles with a covered sample: fetch the three depths (all loads first), then resolve
+    {
+        const float2* zw = sp.zw + (size_t)view * sp.n_verts;
+        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
+        float z0[kTrisPerThread], z1[kTrisPerThread], z2[kTrisPerThread];
+#pragma unroll
+        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+            z0[k] = z1[k] = z2[k] = 0.0f;
+            if (micro_cov[k]) { z0[k] = zw[i0[k]].x; z1[k] = zw[i1[k]].x; z2[k] = zw[i2[k]].x; }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+            if (!micro_cov[k]) continue;
+            const int32_t A = -((r1[k].x - r0[k].x) * (r2[k].y - r0[k].y) - (r2[k].x - r0[k].x) * (r1[k].y - r0[k].y));
+            micro_resolve<S>(micro_edges(r0[k], r1[k], r2[k]), micro_cov[k], (int)(micro_box[k] & 16383u), (int)((micro_box[k] >> 14) & 16383u),
+                             (int)(micro_box[k] >> 28), z0[k], z1[k], z2[k], 1.0f / (float)A, tri[k], vis_view, g);
+        }
+    }
+    if (n_unproj) atomicAdd(&b.counters[kCtrUnprojectable], n_unproj);   // rare
+    // hand the remaining triangles to the binning kernel
+    uint64_t m[kTrisPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+        m[k] = __ballot(pend[k]);
+        if (lane == 0) s_wave[k * 4u + wave] = (uint32_t)__popcll(m[k]);
+    }
+    {
+        uint32_t w = n_micro;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w += (uint32_t)__shfl_down((int)w, o);
+        if (lane == 0) s_micro[wave] = w;
+    }
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread * 4u; ++k) total += s_wave[k];
+    if (tid == 0) {
+        const uint32_t micro = s_micro[0] + s_micro[1] + s_micro[2] + s_micro[3];
+        if (micro) atomicAdd(&b.counters[kCtrMicro], micro);
+        s_base = total ? atomicAdd(&b.pending_total[view], total) : 0u;
+    }
+    if (total == 0) return;   // uniform over the block
+    __syncthreads();
+    uint32_t* list = b.pending + (size_t)view * b.pending_stride + s_base;
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kTrisPerThread; ++k) {
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            if (w == wave && pend[k]) list[run + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))] = tri[k];
+            run += s_wave[k * 4u + w];
+        }
+    }
 }
 
-// Set-up with the vertex stage fused in (see sr_setup_body.inc); pos4: packed positions, views: the
-// transforms of the views of this pass, dirty: optional dirty map (flags == null: not tracked), cull: optional
-// cluster culling (clusters == null: off), clip: optional list for triangles that need near-plane clipping
-// (entries == null: they are dropped and counted).
-template <int S>
-__global__ __launch_bounds__(256) void geometry_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
-                                                       FrameGeom g, BinBuffers b, unsigned long long* __restrict__ vis, uint32_t view0,
-                                                       const float4* __restrict__ pos4, const ViewXform* __restrict__ views, DirtyMap dirty,
-                                                       ClusterCull cull, ClipList clip)
-{
-#define SR_SETUP_FUSED 1
-#include "sr_setup_body.inc"
-#undef SR_SETUP_FUSED
-}
-
-// Binning of the triangles set-up left pending.  Block b takes slice b of the pending list, in a
-// permuted order so that blocks running at the same time work on distant parts of the mesh.
+// Binning of the triangles set-up left pending.  The view's pending list is taken in chunks of kBlockTris
+// triangles by a fixed number of workgroups; the chunks are visited in a scrambled order (odd multiplier
+// modulo a power of two) so that workgroups running at the same time work on distant parts of the list --
+// neighbouring chunks come from neighbouring parts of the mesh and would pile their per-tile atomics on
+// the same counters.  A frame of sub-pixel triangles leaves next to nothing pending: all but one
+// workgroup then leave at once.
 template <int S>
 __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ idx, ScreenPlanes sp, FrameGeom g, BinBuffers b)
 {
@@ -245,13 +302,19 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
     __shared__ uint32_t s_total;
     const uint32_t view = blockIdx.y;
     const uint32_t tid = threadIdx.x;
-    const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * b.block_stride) % b.n_blocks);
     const uint32_t lane = lane_id();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
-    const uint32_t n = b.pending_count[(size_t)view * b.n_blocks + blk];
-    if (tid == 0) b.block_count[(size_t)view * b.n_blocks + blk] = 0u;
-    if (n == 0) return;   // uniform over the block
+    const uint32_t n_pending = min(b.pending_total[view], b.pending_stride);
+    const uint32_t n_chunks = (n_pending + kBlockTris - 1u) / kBlockTris;
+    uint32_t span_chunks = 1u;
+    while (span_chunks < n_chunks) span_chunks <<= 1;
+    const uint32_t scramble = ((uint32_t)((float)span_chunks * 0.6180339887f) | 1u);   // odd: a bijection modulo span_chunks
+    for (uint32_t turn = blockIdx.x; turn < span_chunks; turn += gridDim.x) {
+    const uint32_t blk = (turn * scramble) & (span_chunks - 1u);
+    if (blk >= n_chunks) continue;   // uniform over the block
+    const uint32_t n = min(kBlockTris, n_pending - blk * kBlockTris);
+    __syncthreads();   // the tables of the previous chunk are no longer in use
     uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
     uint32_t* count_large = b.count_large + (size_t)view * n_tiles;
 #pragma unroll
@@ -261,7 +324,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
     }
     if (tid == 0) s_total = 0u;
 
-    const uint32_t* slice = b.pending + ((size_t)view * b.n_blocks + blk) * kBlockTris;
+    const uint32_t* slice = b.pending + (size_t)view * b.pending_stride + (size_t)blk * kBlockTris;
     const int2* xy = sp.xy + (size_t)view * sp.n_verts;
     uint32_t tri[kTrisPerThread], i0[kTrisPerThread], i1[kTrisPerThread], i2[kTrisPerThread];
     bool have[kTrisPerThread];
@@ -400,6 +463,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
         }
     }
     if (tid == 0) b.block_count[(size_t)view * b.n_blocks + blk] = s_total;
+    }
 }
 
 // =================================================================================================
@@ -407,12 +471,10 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
 // =================================================================================================
 __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ count_a, const uint32_t* __restrict__ count_b, uint32_t n,
                                                     uint32_t* __restrict__ offset, uint32_t* __restrict__ counters,
-                                                    const uint32_t* __restrict__ block_live, uint32_t n_block_counts,
+                                                    const uint32_t* __restrict__ pending_total, uint32_t n_views,
                                                     uint32_t* __restrict__ host_counters)
 {
     __shared__ uint32_t part[1024];
-    __shared__ uint32_t s_sum[2];
-    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0u;
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t beg = min(tid * per, n), end = min(beg + per, n);
@@ -428,18 +490,15 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
     }
     uint32_t run = part[tid] - s;
     for (uint32_t i = beg; i < end; ++i) { offset[i] = run; run += count_a[i] + count_b[i]; }
-    if (tid == 1023u) { offset[n] = part[1023]; counters[0] = part[1023]; }
-    // number of binned triangles (instrumentation)
-    uint32_t surv = 0, micro = 0;
-    for (uint32_t i = tid; i < n_block_counts; i += 1024u) { const uint32_t v = block_live[i]; surv += v & 0xFFFFu; micro += v >> 16; }
-    for (int o = 32; o > 0; o >>= 1) { surv += (uint32_t)__shfl_down((int)surv, o); micro += (uint32_t)__shfl_down((int)micro, o); }
-    if ((tid & 63u) == 0u) { atomicAdd(&s_sum[0], surv); atomicAdd(&s_sum[1], micro); }
-    __syncthreads();
+    if (tid == 1023u) { offset[n] = part[1023]; counters[kCtrRefs] = part[1023]; }
     if (tid == 0) {
         // results of the pass for the host, written straight into pinned host memory (read after the
-        // stream has been synchronised): total references, -, unprojectable, binned, direct
-        host_counters[0] = part[1023]; host_counters[1] = 0u; host_counters[2] = counters[2];
-        host_counters[3] = s_sum[0]; host_counters[4] = s_sum[1];
+        // stream has been synchronised): total references, -, unprojectable, binned, direct, -, clipped
+        uint32_t binned = 0;
+        for (uint32_t v = 0; v < n_views; ++v) binned += pending_total[v];
+        host_counters[0] = part[1023]; host_counters[1] = 0u; host_counters[2] = counters[kCtrUnprojectable];
+        host_counters[3] = binned; host_counters[4] = counters[kCtrMicro]; host_counters[5] = 0u;
+        host_counters[6] = counters[kCtrClipped];
     }
 }
 
@@ -455,21 +514,24 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameGeom g, BinBuffers b)
     const uint32_t* offset = b.tile_offset + (size_t)view * n_tiles;
     const uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
     uint32_t* cursor_large = b.cursor_large + (size_t)view * n_tiles;
-    const uint32_t n = b.block_count[(size_t)view * b.n_blocks + blockIdx.x];
-    const BinRecord* seg = b.records + ((size_t)view * b.n_blocks + blockIdx.x) * kBlockRecords;
-    for (uint32_t i = tid; i < n; i += 256u) {
-        const BinRecord rec = seg[i];
-        if (rec.rel != kLargeTri) {
-            const uint32_t pos = offset[rec.where] + rec.rel;
-            if (pos < b.ref_capacity) b.refs[pos] = rec.tri; else atomicAdd(&b.counters[1], 1u);
-        } else {
-            const int tx0 = rec.where & 255, ty0 = (rec.where >> 8) & 255, tx1 = (rec.where >> 16) & 255, ty1 = rec.where >> 24;
-            for (int ty = ty0; ty <= ty1; ++ty)
-                for (int tx = tx0; tx <= tx1; ++tx) {
-                    const uint32_t tile = (uint32_t)(ty * g.tiles_x + tx);
-                    const uint32_t pos = offset[tile] + count_small[tile] + atomicAdd(&cursor_large[tile], 1u);
-                    if (pos < b.ref_capacity) b.refs[pos] = rec.tri; else atomicAdd(&b.counters[1], 1u);
-                }
+    const uint32_t n_chunks = (min(b.pending_total[view], b.pending_stride) + kBlockTris - 1u) / kBlockTris;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t n = min(b.block_count[(size_t)view * b.n_blocks + chunk], kBlockRecords);
+        const BinRecord* seg = b.records + ((size_t)view * b.n_blocks + chunk) * kBlockRecords;
+        for (uint32_t i = tid; i < n; i += 256u) {
+            const BinRecord rec = seg[i];
+            if (rec.rel != kLargeTri) {
+                const uint32_t pos = offset[rec.where] + rec.rel;
+                if (pos < b.ref_capacity) b.refs[pos] = rec.tri; else atomicAdd(&b.counters[kCtrRefsDropped], 1u);
+            } else {
+                const int tx0 = rec.where & 255, ty0 = (rec.where >> 8) & 255, tx1 = (rec.where >> 16) & 255, ty1 = rec.where >> 24;
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) {
+                        const uint32_t tile = (uint32_t)(ty * g.tiles_x + tx);
+                        const uint32_t pos = offset[tile] + count_small[tile] + atomicAdd(&cursor_large[tile], 1u);
+                        if (pos < b.ref_capacity) b.refs[pos] = rec.tri; else atomicAdd(&b.counters[kCtrRefsDropped], 1u);
+                    }
+            }
         }
     }
 }
@@ -524,10 +586,10 @@ __device__ inline void raster_pixel32(const TriSetup& ts, uint32_t tri, int x, i
     }
 }
 
-template <int TL2, int S, int TPB, bool DIRTY = false>
+template <int TL2, int S, int TPB>
 __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                      FrameGeom g, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ refs,
-                                                     uint32_t ref_capacity, unsigned long long* __restrict__ vis, uint32_t view0, DirtyMap dirty)
+                                                     uint32_t ref_capacity, unsigned long long* __restrict__ vis, uint32_t view0)
 {
     constexpr int T = 1 << TL2;
     constexpr int kSmall = 16;   // bounding boxes up to this many pixels are walked by one lane
@@ -648,127 +710,28 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
     for (int i = tid; i < T * T * S; i += TPB) {
         const int s = i % S, p = i / S, lx = p & (T - 1), ly = p >> TL2;
         // merge with what micro-triangles already resolved in HBM; untouched samples cost nothing
-        if (lx < tw && ly < th && tile[i] != kVisClear) {
+        if (lx < tw && ly < th && tile[i] != kVisClear)
             atomicMin(&out[((size_t)(py0 - g.ry + ly) * g.rw + (px0 - g.rx + lx)) * S + s], tile[i]);
-            if constexpr (DIRTY) mark_dirty(dirty, view0 + view, px0 - g.rx + lx, py0 - g.ry + ly);
-        }
     }
 }
 
 // =================================================================================================
-// stage 3': sparse tail (pipeline variant).  A frame of sub-pixel triangles leaves next to nothing for
-// the tile lists (115 of 10 M triangles in the 4K sphere frame), yet binning, scan, fill and the
-// per-tile pass each cost a launch.  When the previous frame of a target left few triangles pending
-// the host issues this kernel in their place: every wave takes pending triangles straight from the
-// set-up blocks' lists and resolves them into the visibility buffer in HBM with the same edge
-// functions, depth expression and 64-bit min as every other path, 8x8 pixels per step.  Correct for
-// any number and size of triangles, just not fast for many large ones -- the counters it reports
-// (pending triangles, 8x8 steps) send the next frame back to the tile lists in that case.
+// near-plane clipping (see sr_device.h)
 // =================================================================================================
-template <int S>
-__global__ __launch_bounds__(256) void sparse_tail_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp, FrameGeom g, BinBuffers b,
-                                                          unsigned long long* __restrict__ vis, uint32_t view0, uint32_t n_views, DirtyMap dirty,
-                                                          uint32_t* __restrict__ host_counters)
-{
-    __shared__ uint32_t s_sum[3];   // pending triangles, micro-triangles, 8x8 steps
-    if (threadIdx.x < 3u) s_sum[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t lane = lane_id();
-    const uint32_t waves_total = gridDim.x * 4u, first = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t n_slices = n_views * b.n_blocks;
-    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
-    uint32_t n_pending = 0, n_micro = 0, n_steps = 0;
-    for (uint32_t slice = first; slice < n_slices; slice += waves_total) {   // one set-up block's list per turn; every lane of the wave holds the same triangle
-        const uint32_t live = b.block_live[slice];
-        const uint32_t count = live & 0xFFFFu, view = slice / b.n_blocks;
-        n_pending += count; n_micro += live >> 16;
-        const int2* xy = sp.xy + (size_t)view * sp.n_verts;
-        const float2* zw = sp.zw + (size_t)view * sp.n_verts;
-        unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
-        for (uint32_t t = 0; t < count; ++t) {
-            const uint32_t tri = b.pending[(size_t)slice * kBlockTris + t];
-            if (tri >= n_tris) continue;   // (lists only ever hold valid ids; cheap insurance against a fault)
-            const uint32_t i0 = idx[3 * (size_t)tri], i1 = idx[3 * (size_t)tri + 1], i2 = idx[3 * (size_t)tri + 2];
-            const int2 a0 = xy[i0], a1 = xy[i1], a2 = xy[i2];
-            ScreenVertex v0, v1, v2;
-            v0.X = a0.x; v0.Y = a0.y; v0.z = zw[i0].x; v0.rw = a0.x == kBadVertexX ? 0.0f : 1.0f;
-            v1.X = a1.x; v1.Y = a1.y; v1.z = zw[i1].x; v1.rw = a1.x == kBadVertexX ? 0.0f : 1.0f;
-            v2.X = a2.x; v2.Y = a2.y; v2.z = zw[i2].x; v2.rw = a2.x == kBadVertexX ? 0.0f : 1.0f;
-            TriSetup ts;
-            if (setup_triangle(v0, v1, v2, ts) != 1) continue;
-            int x0, x1, y0, y1;
-            pixel_span<S>(ts.minX, ts.maxX, x0, x1);
-            pixel_span<S>(ts.minY, ts.maxY, y0, y1);
-            x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
-            y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
-            const bool narrow = fits_32bit(ts);
-            for (int by = y0; by <= y1; by += 8)
-                for (int bx = x0; bx <= x1; bx += 8) {
-                    ++n_steps;
-                    const int x = bx + lx, y = by + ly;
-                    if (x <= x1 && y <= y1) {
-                        unsigned long long* cell = &vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S];
-                        if (narrow) raster_pixel32<S>(ts, tri, x, y, cell);
-                        else raster_pixel<S>(ts, tri, x, y, cell);
-                    }
-                    // the step's four corner lanes mark the (at most four) blocks of the dirty map under it
-                    if (dirty.flags && (lx == 0 || lx == 7) && (ly == 0 || ly == 7))
-                        mark_dirty(dirty, view0 + view, min(x, x1) - g.rx, min(y, y1) - g.ry);
-                }
-        }
-    }
-    if (lane == 0u) { atomicAdd(&s_sum[0], n_pending); atomicAdd(&s_sum[1], n_micro); atomicAdd(&s_sum[2], n_steps); }
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        // totals of the pass for the host: the workgroup that finishes last writes them to pinned host memory
-        atomicAdd(&b.counters[3], s_sum[0]); atomicAdd(&b.counters[4], s_sum[1]); atomicAdd(&b.counters[5], s_sum[2]);
-        __threadfence();
-        if (atomicAdd(&b.counters[6], 1u) == gridDim.x - 1u) {
-            __threadfence();
-            host_counters[0] = 0u; host_counters[1] = 0u;
-            host_counters[2] = atomicAdd(&b.counters[2], 0u);
-            host_counters[3] = atomicAdd(&b.counters[3], 0u);
-            host_counters[4] = atomicAdd(&b.counters[4], 0u);
-            host_counters[5] = atomicAdd(&b.counters[5], 0u);
-        }
-    }
-}
-
-// =================================================================================================
-// near-plane clipping (pipeline variant, see sr_device.h)
-// =================================================================================================
-// Without the fused set-up kernel nothing lists the triangles: the plain set-up kernel only counts them.  When it counted
-// any, this kernel goes over the triangles of the pass once more, finds those with one or two unprojectable vertices in
-// the vertex kernel's planes, lists them and takes them off the count again (a full list leaves them on it).
-__global__ __launch_bounds__(256) void clip_scan_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, uint32_t n_views, ScreenPlanes sp, ClipList clip,
-                                                        uint32_t* __restrict__ counters)
-{
-    if (counters[2] == 0u) return;   // the same for every work-item: the usual frame ends here
-    const uint64_t total = (uint64_t)n_tris * n_views;
-    for (uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x; e < total; e += (uint64_t)gridDim.x * 256u) {
-        const uint32_t view = (uint32_t)(e / n_tris), tri = (uint32_t)(e % n_tris);
-        const int2* xy = sp.xy + (size_t)view * sp.n_verts;
-        const int bad = (xy[idx[3 * (size_t)tri]].x == kBadVertexX) + (xy[idx[3 * (size_t)tri + 1]].x == kBadVertexX) + (xy[idx[3 * (size_t)tri + 2]].x == kBadVertexX);
-        if (bad == 0 || bad == 3) continue;
-        const uint32_t slot = atomicAdd(clip.count, 1u);
-        if (slot < clip.capacity) { clip.entries[slot] = make_uint2(view, tri); atomicSub(&counters[2], 1u); }
-    }
-}
-
 // One kernel cuts the listed triangles and resolves the pieces into the visibility buffer in HBM, 8x8 pixels per step.
 // A work item is (listed triangle, slab): the rows of 8x8 blocks of a piece's box are dealt out to kClipSlabs waves, so
 // that a piece that fills the frame does not hang on one wave; every lane of a wave computes the same polygon (a few
-// hundred instructions, nothing next to the steps of a large piece).  pos4: packed positions (fused set-up), or null:
-// the three position planes px, py, pz.  The workgroup that finishes last writes the number of triangles clipped
-// to host_counters[6].
+// hundred instructions, nothing next to the steps of a large piece).  Positions come from the three planes px, py, pz
+// and are projected with the vertex kernel's own function, so a projectable vertex gets the window position its
+// neighbours were rasterised with.  The list is empty in any ordinary frame: every wave then leaves at once.
 constexpr uint32_t kClipSlabs = 16;
 template <int S>
-__global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, const float4* __restrict__ pos4,
+__global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris,
                                                         const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                         const ViewXform* __restrict__ views, FrameGeom g, ClipList clip, uint32_t* __restrict__ counters,
-                                                        unsigned long long* __restrict__ vis, uint32_t view0, DirtyMap dirty, uint32_t* __restrict__ host_counters)
+                                                        unsigned long long* __restrict__ vis, uint32_t view0)
 {
-    const uint32_t n = min(*clip.count, clip.capacity);
+    const uint32_t n = min(counters[kCtrClipListed], clip.capacity);
     const uint32_t lane = lane_id();
     const uint32_t waves_total = gridDim.x * 4u, first = blockIdx.x * 4u + (threadIdx.x >> 6);
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
@@ -782,8 +745,7 @@ __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restri
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const uint32_t i = idx[3 * (size_t)tri + k];
-            const float4 q = pos4 ? pos4[i] : make_float4(px[i], py[i], pz[i], 1.0f);
-            sv[k] = project_vertex_short(views[view], q.x, q.y, q.z, g.W, g.H, c[k]);
+            sv[k] = project_vertex(views[view], px[i], py[i], pz[i], g.W, g.H, c[k]);
         }
         ScreenVertex poly[kClipMaxVertices];
         const int np = near_clip_polygon(c, sv, g.W, g.H, poly);
@@ -810,23 +772,12 @@ __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restri
                         if (narrow) raster_pixel32<S>(ts, tri, x, y, cell);
                         else raster_pixel<S>(ts, tri, x, y, cell);
                     }
-                    // the step's four corner lanes mark the (at most four) blocks of the dirty map under it
-                    if (dirty.flags && (lx == 0 || lx == 7) && (ly == 0 || ly == 7))
-                        mark_dirty(dirty, view0 + view, min(x, x1) - g.rx, min(y, y1) - g.ry);
                 }
         }
     }
     if (lane == 0u) {
-        if (n_dropped) atomicAdd(&counters[2], n_dropped);
-        if (n_clipped) atomicAdd(&clip.state[1], n_clipped);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        __threadfence();
-        if (atomicAdd(&clip.state[2], 1u) == gridDim.x - 1u) {
-            __threadfence();
-            host_counters[6] = atomicAdd(&clip.state[1], 0u);
-        }
+        if (n_dropped) atomicAdd(&counters[kCtrUnprojectable], n_dropped);
+        if (n_clipped) atomicAdd(&counters[kCtrClipped], n_clipped);
     }
 }
 
@@ -922,11 +873,13 @@ __device__ inline void sample_texture(const TexDesc& t, const uint32_t* lvl, flo
 // texture() with the sampler's anisotropy applied, by the method the Vulkan specification spells out (Scale
 // Factor Operation / Texel Anisotropic Filtering): eta = min(rho_max / rho_min, max_aniso), N = ceil(eta),
 // level of detail from rho_max / eta, and the mean of N trilinear samples placed at i / (N + 1) - 1/2,
-// i = 1..N, along the derivative of the major axis.  Pipeline variant "anisotropic" only.
+// i = 1..N, along the derivative of the major axis.  A sampler with maxAnisotropy <= 1 gets the isotropic footprint.
 template <int NCH>
-__device__ inline void sample_texture_aniso(const TexDesc& t, const uint32_t* lvl, float max_aniso, float s, float tt, float dsdx, float dtdx,
+__device__ inline void sample_texture_aniso(const TexDesc& t, const uint32_t* lvl, float s, float tt, float dsdx, float dtdx,
                                             float dsdy, float dtdy, const float* dec, float* o)
 {
+    const float max_aniso = t.max_aniso;
+    if (!(max_aniso > 1.0f)) { sample_texture<NCH>(t, lvl, s, tt, dsdx, dtdx, dsdy, dtdy, dec, o); return; }   // uniform over the launch
     const float mux = dsdx * (float)t.w, mvx = dtdx * (float)t.h;
     const float muy = dsdy * (float)t.w, mvy = dtdy * (float)t.h;
     const float rx2 = mux * mux + mvx * mvx, ry2 = muy * muy + mvy * mvy;
@@ -1051,7 +1004,6 @@ __device__ inline void fragment_main(const float* wp, const float* N, const floa
 struct FragParams {
     const uint32_t* idx;
     const float4* verts;       // 2 float4 per vertex: (pos.xyz, n.x) (n.yz, uv)
-    ScreenPlanes screen;       // window-space vertices of the views of this pass
     const ViewXform* views;    // views of this pass
     const unsigned long long* vis;
     uint32_t* color;
@@ -1059,103 +1011,59 @@ struct FragParams {
     TexDesc albedo, metallic, roughness;
     ShadeTables tab;
     uint32_t view0;            // first view of this pass inside the target
-    DirtyMap dirty;            // read by fragment_kernel<S, true> only
-    float max_aniso;           // the sampler's maxAnisotropy; used by fragment_kernel<S, true, true, true> only
 };
 
-// window-space position and 1/w of a vertex of a visible triangle (so w > 0), for interpolation only
-__device__ inline ScreenVertex shading_vertex(const ViewXform& vx, float px, float py, float pz, int W, int H)
-{
-#pragma clang fp contract(fast)
-    float wp[4], clip[4];
-    mat4_mul_vec4(vx.model, px, py, pz, 1.0f, wp);
-    mat4_mul_vec4(vx.pv, wp[0], wp[1], wp[2], 1.0f, clip);
-    ScreenVertex sv;
-    const float rw = frcp(clip[3]);
-    const float hw = (float)W * 0.5f, hh = (float)H * 0.5f;
-    sv.X = (int32_t)rintf((clip[0] * rw * hw + hw) * (float)kSubpix);
-    sv.Y = (int32_t)rintf((clip[1] * rw * (-hh) + hh) * (float)kSubpix);
-    sv.z = 0.0f;
-    sv.rw = rw;
-    return sv;
-}
-
-// shades triangle `tri` at pixel (x,y): packed B,G,R,A.  Barycentrics are evaluated in float relative
-// to vertex 0 (exact for triangles up to a few hundred pixels, 2^-24 relative otherwise); the values
-// at the other pixels of the 2x2 quad follow from their screen-space gradients.
-// EXACT: the window-space vertices are recomputed with the vertex stage's own arithmetic (IEEE divide,
-// no contraction) and so are bit-identical to the ones the triangle was rasterised from; the default
-// uses the hardware reciprocal, which can land a vertex on the neighbouring 1/256-pixel position --
-// invisible on ordinary triangles, but on slivers a fraction of a pixel wide it shifts the texture
-// gradients (and can collapse the area to zero).
-template <bool EXACT = false, bool ANISO = false>
-__device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, size_t sv_base, uint32_t tri, int x, int y,
+// shades triangle `tri` at pixel (x,y): packed B,G,R,A.  The window-space vertices are recomputed from
+// the positions just loaded instead of gathered from the vertex stage's planes (six divergent loads cost
+// the CU's address/cache path far more than the arithmetic), with the vertex stage's own function
+// (IEEE divide, no contraction), so they are bit-identical to the ones the triangle was rasterised from.
+// Each barycentric weight comes from its own cross product of the two opposite vertices seen from the
+// pixel, so its error is relative to its own size (a form like l0 = 1 - l1 - l2 around vertex 0 loses l0
+// when vertex 0 is far away and close to the eye plane: its huge 1/w then multiplies the rounding
+// error of l1 + l2); the values at the other pixels of the 2x2 quad follow from the screen-space
+// gradients.
+template <bool ANISO>
+__device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, uint32_t tri, int x, int y,
                                        const float* dec, const float* thr, const uint32_t* lvl /* [3][kMaxMipLevels] */)
 {
     const uint32_t i0 = p.idx[3 * (size_t)tri], i1 = p.idx[3 * (size_t)tri + 1], i2 = p.idx[3 * (size_t)tri + 2];
     const float4 a0 = p.verts[2 * (size_t)i0], b0 = p.verts[2 * (size_t)i0 + 1];
     const float4 a1 = p.verts[2 * (size_t)i1], b1 = p.verts[2 * (size_t)i1 + 1];
     const float4 a2 = p.verts[2 * (size_t)i2], b2 = p.verts[2 * (size_t)i2 + 1];
-    // window-space vertices are recomputed from the positions just loaded instead of gathered from the
-    // vertex stage's planes: six divergent loads cost the CU's address/cache path far more than
-    // ~45 arithmetic instructions per vertex.  (Reciprocal instead of division: at worst a vertex lands
-    // on the neighbouring 1/256-pixel position, which moves no colour by an 8-bit step.)
-    ScreenVertex v0, v1, v2;
-    if constexpr (EXACT) {
-        float clip[4];
-        v0 = project_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H, clip);
-        v1 = project_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H, clip);
-        v2 = project_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H, clip);
-    } else {
-        v0 = shading_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H);
-        v1 = shading_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H);
-        v2 = shading_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H);
-    }
-    // edge vectors relative to v0, 1/256 pixel; weights: l1 = cross(p - v0, e2) / A', l2 = cross(e1, p - v0) / A'
-    const float e1x = (float)(v1.X - v0.X), e1y = (float)(v1.Y - v0.Y);
-    const float e2x = (float)(v2.X - v0.X), e2y = (float)(v2.Y - v0.Y);
-    const float dx = (float)(x * kSubpix + kHalf - v0.X), dy = (float)(y * kSubpix + kHalf - v0.Y);
-    float rA, l0, l1, l2;
-    if constexpr (EXACT) {
-        // Each weight from its own cross product of the two opposite vertices seen from the pixel: its error is
-        // relative to its own size.  (The form below, l0 = 1 - l1 - l2 around vertex 0, loses l0 when vertex 0 is
-        // far away and close to the eye plane: its huge 1/w then multiplies the rounding error of l1 + l2.)
+    float c0[4], c1[4], c2[4];
+    const ScreenVertex v0 = project_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H, c0);
+    const ScreenVertex v1 = project_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H, c1);
+    const ScreenVertex v2 = project_vertex(vx, a2.x, a2.y, a2.z, p.g.W, p.g.H, c2);
+    float q0, q1, q2, q0x, q1x, q2x, q0y, q1y, q2y;
+    if (v0.rw != 0.0f && v1.rw != 0.0f && v2.rw != 0.0f) {
         const int32_t px = x * kSubpix + kHalf, py = y * kSubpix + kHalf;
+        const float e1x = (float)(v1.X - v0.X), e1y = (float)(v1.Y - v0.Y);
+        const float e2x = (float)(v2.X - v0.X), e2y = (float)(v2.Y - v0.Y);
         const float a0x = (float)(v0.X - px), a0y = (float)(v0.Y - py), a1x = (float)(v1.X - px), a1y = (float)(v1.Y - py);
         const float a2x = (float)(v2.X - px), a2y = (float)(v2.Y - py);
         const float E0 = a1x * a2y - a1y * a2x, E1 = a2x * a0y - a2y * a0x, E2 = a0x * a1y - a0y * a1x;
-        rA = frcp((E0 + E1) + E2);
-        l0 = E0 * rA; l1 = E1 * rA; l2 = E2 * rA;
+        const float rA = frcp((E0 + E1) + E2);
+        const float l0 = E0 * rA, l1 = E1 * rA, l2 = E2 * rA;
+        // gradients per pixel step (256 sub-pixels)
+        const float s = (float)kSubpix * rA;
+        const float l1x = e2y * s, l1y = -e2x * s, l2x = -e1y * s, l2y = e1x * s;
+        // perspective: attribute = sum(q_i a_i) / sum(q_i), q_i = l_i / w_i, all affine in screen space
+        q0 = l0 * v0.rw; q1 = l1 * v1.rw; q2 = l2 * v2.rw;
+        q0x = -(l1x + l2x) * v0.rw; q1x = l1x * v1.rw; q2x = l2x * v2.rw;
+        q0y = -(l1y + l2y) * v0.rw; q1y = l1y * v1.rw; q2y = l2y * v2.rw;
     } else {
-        rA = frcp(e1x * e2y - e1y * e2x);
-        l1 = (dx * e2y - dy * e2x) * rA; l2 = (e1x * dy - e1y * dx) * rA; l0 = 1.0f - l1 - l2;
-    }
-    // gradients per pixel step (256 sub-pixels)
-    const float s = (float)kSubpix * rA;
-    const float l1x = e2y * s, l1y = -e2x * s, l2x = -e1y * s, l2y = e1x * s;
-    // perspective: attribute = sum(q_i a_i) / sum(q_i), q_i = l_i / w_i, all affine in screen space
-    float q0 = l0 * v0.rw, q1 = l1 * v1.rw, q2 = l2 * v2.rw;
-    float q0x = -(l1x + l2x) * v0.rw, q1x = l1x * v1.rw, q2x = l2x * v2.rw;
-    float q0y = -(l1y + l2y) * v0.rw, q1y = l1y * v1.rw, q2y = l2y * v2.rw;
-    if constexpr (EXACT) {
-        if (v0.rw == 0.0f || v1.rw == 0.0f || v2.rw == 0.0f) {
-            // A triangle that reached the frame through the near-plane clipper: a vertex has no window position, so
-            // the weights come from the clip-space coordinates (x, y, w).  With h_i = (x_i - w_i X, y_i - w_i Y) for
-            // the pixel's normalised device coordinates (X, Y), q_i is proportional to cross(h_j, h_k), affine in
-            // (X, Y) like the q_i above (any common factor cancels in the divisions by D below).
-            float wpos[4], c0[4], c1[4], c2[4];
-            mat4_mul_vec4(vx.model, a0.x, a0.y, a0.z, 1.0f, wpos); mat4_mul_vec4(vx.pv, wpos[0], wpos[1], wpos[2], 1.0f, c0);
-            mat4_mul_vec4(vx.model, a1.x, a1.y, a1.z, 1.0f, wpos); mat4_mul_vec4(vx.pv, wpos[0], wpos[1], wpos[2], 1.0f, c1);
-            mat4_mul_vec4(vx.model, a2.x, a2.y, a2.z, 1.0f, wpos); mat4_mul_vec4(vx.pv, wpos[0], wpos[1], wpos[2], 1.0f, c2);
-            const float hw = (float)p.g.W * 0.5f, hh = (float)p.g.H * 0.5f, ihw = 1.0f / hw, ihh = 1.0f / hh;
-            const float X = ((float)x + 0.5f - hw) * ihw, Y = (hh - ((float)y + 0.5f)) * ihh;
-            const float h0x = c0[0] - c0[3] * X, h0y = c0[1] - c0[3] * Y, h1x = c1[0] - c1[3] * X, h1y = c1[1] - c1[3] * Y;
-            const float h2x = c2[0] - c2[3] * X, h2y = c2[1] - c2[3] * Y;
-            q0 = h1x * h2y - h1y * h2x; q1 = h2x * h0y - h2y * h0x; q2 = h0x * h1y - h0y * h1x;
-            q0x = -(c1[3] * h2y - h1y * c2[3]) * ihw; q0y = (h1x * c2[3] - c1[3] * h2x) * ihh;   // one pixel to the right: X + 1/hw; down: Y - 1/hh
-            q1x = -(c2[3] * h0y - h2y * c0[3]) * ihw; q1y = (h2x * c0[3] - c2[3] * h0x) * ihh;
-            q2x = -(c0[3] * h1y - h0y * c1[3]) * ihw; q2y = (h0x * c1[3] - c0[3] * h1x) * ihh;
-        }
+        // A triangle that reached the frame through the near-plane clipper: a vertex has no window position, so
+        // the weights come from the clip-space coordinates (x, y, w).  With h_i = (x_i - w_i X, y_i - w_i Y) for
+        // the pixel's normalised device coordinates (X, Y), q_i is proportional to cross(h_j, h_k), affine in
+        // (X, Y) like the q_i above (any common factor cancels in the divisions by D below).
+        const float hw = (float)p.g.W * 0.5f, hh = (float)p.g.H * 0.5f, ihw = 1.0f / hw, ihh = 1.0f / hh;
+        const float X = ((float)x + 0.5f - hw) * ihw, Y = (hh - ((float)y + 0.5f)) * ihh;
+        const float h0x = c0[0] - c0[3] * X, h0y = c0[1] - c0[3] * Y, h1x = c1[0] - c1[3] * X, h1y = c1[1] - c1[3] * Y;
+        const float h2x = c2[0] - c2[3] * X, h2y = c2[1] - c2[3] * Y;
+        q0 = h1x * h2y - h1y * h2x; q1 = h2x * h0y - h2y * h0x; q2 = h0x * h1y - h0y * h1x;
+        q0x = -(c1[3] * h2y - h1y * c2[3]) * ihw; q0y = (h1x * c2[3] - c1[3] * h2x) * ihh;   // one pixel to the right: X + 1/hw; down: Y - 1/hh
+        q1x = -(c2[3] * h0y - h2y * c0[3]) * ihw; q1y = (h2x * c0[3] - c2[3] * h0x) * ihh;
+        q2x = -(c0[3] * h1y - h0y * c1[3]) * ihw; q2y = (h0x * c1[3] - c0[3] * h1x) * ihh;
     }
     const float D = q0 + q1 + q2, Dx = q0x + q1x + q2x, Dy = q0y + q1y + q2y;
     const float Nu = fmaf(q2, b2.z, fmaf(q1, b1.z, q0 * b0.z)), Nv = fmaf(q2, b2.w, fmaf(q1, b1.w, q0 * b0.w));
@@ -1185,9 +1093,9 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     for (int k = 0; k < 3; ++k) { wp[k] = fmaf(p2, w2[k], fmaf(p1, w1[k], p0 * w0[k])); N[k] = fmaf(p2, n2[k], fmaf(p1, n1[k], p0 * n0[k])); }
     float alb[3], met[1], rgh[1], rgb[3];
     if constexpr (ANISO) {
-        sample_texture_aniso<3>(p.albedo, lvl, p.max_aniso, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
-        sample_texture_aniso<1>(p.metallic, lvl + kMaxMipLevels, p.max_aniso, u, v, dudx, dvdx, dudy, dvdy, dec, met);
-        sample_texture_aniso<1>(p.roughness, lvl + 2 * kMaxMipLevels, p.max_aniso, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+        sample_texture_aniso<3>(p.albedo, lvl, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
+        sample_texture_aniso<1>(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, met);
+        sample_texture_aniso<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
     } else {
         sample_texture<3>(p.albedo, lvl, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
         sample_texture<1>(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, met);
@@ -1200,36 +1108,34 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     return B | (G << 8) | (R << 16) | (255u << 24);
 }
 
-template <int S, bool DIRTY = false, bool EXACT = false, bool ANISO = false>
+// One work-item per pixel, workgroups of kFragBlockW x kFragBlockH pixels.  The launch shape and the
+// indexing of the 256-entry tables below are tied together by these two constants and the assertion.
+constexpr uint32_t kFragBlockW = 32, kFragBlockH = 8;
+static_assert(kFragBlockW * kFragBlockH == 256, "the tables of the shading kernel are filled by 256 work-items");
+
+template <int S, bool ANISO>
 __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
 {
     __shared__ float s_dec[256];
     __shared__ float s_thr[256];
     __shared__ uint32_t s_lvl[3 * kMaxMipLevels];
-    const uint32_t tid = threadIdx.y * 32u + threadIdx.x;
-    if constexpr (DIRTY) {
-        // the workgroup is one block of the dirty map: nothing was drawn into a clean block
-        if (p.dirty.flags[((size_t)(p.view0 + blockIdx.z) * p.dirty.nby + blockIdx.y) * p.dirty.nbx + blockIdx.x] == 0u) {
-            const int cx = (int)(blockIdx.x * 32u + threadIdx.x), cy = (int)(blockIdx.y * 8u + threadIdx.y);
-            if (cx < p.g.rw && cy < p.g.rh) p.color[((size_t)(p.view0 + blockIdx.z) * p.g.rh + cy) * p.g.rw + cx] = kColorClear;
-            return;
-        }
+    const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid < 256u) {   // (always: the launcher uses kFragBlockW x kFragBlockH; a different shape must not index past the tables)
+        s_dec[tid] = p.tab.decode[tid];
+        s_thr[tid] = tid < 255u ? p.tab.thresh[tid] : 3.0e38f;
     }
-    s_dec[tid] = p.tab.decode[tid];
-    s_thr[tid] = tid < 255u ? p.tab.thresh[tid] : 3.0e38f;
     if (tid < 3u * kMaxMipLevels) {
         const uint32_t m = tid / kMaxMipLevels, l = tid % kMaxMipLevels;
         s_lvl[tid] = m == 0 ? p.albedo.level_off[l] : m == 1 ? p.metallic.level_off[l] : p.roughness.level_off[l];
     }
     __syncthreads();
-    const int lx = (int)(blockIdx.x * 32u + threadIdx.x), ly = (int)(blockIdx.y * 8u + threadIdx.y);
+    const int lx = (int)(blockIdx.x * blockDim.x + threadIdx.x), ly = (int)(blockIdx.y * blockDim.y + threadIdx.y);
     const uint32_t view = blockIdx.z;
     if (lx >= p.g.rw || ly >= p.g.rh) return;
     const size_t pix = ((size_t)(p.view0 + view) * p.g.rh + ly) * p.g.rw + lx;
     const unsigned long long* v = p.vis + pix * S;
     const int x = p.g.rx + lx, y = p.g.ry + ly;
     const ViewXform& vx = p.views[view];
-    const size_t sv = (size_t)view * p.screen.n_verts;
     uint32_t ids[S], col[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) ids[s] = (uint32_t)v[s];
@@ -1245,7 +1151,7 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
             for (int k = 0; k < s; ++k) if (k == prev) c = col[k];
             col[s] = c;
         } else {
-            col[s] = shade_pixel<EXACT, ANISO>(p, vx, sv, ids[s], x, y, s_dec, s_thr, s_lvl);
+            col[s] = shade_pixel<ANISO>(p, vx, ids[s], x, y, s_dec, s_thr, s_lvl);
         }
     }
     uint32_t outc;
@@ -1271,10 +1177,13 @@ __global__ __launch_bounds__(256) void fragment_kernel(FragParams p)
 // =================================================================================================
 // mip-chain builder: one linear blit per level (src/texture.cpp:119-164), sRGB-correct
 // =================================================================================================
+// a workgroup of kMipBlockW * kMipBlockH work-items (one-dimensional) covers kMipBlockW x kMipBlockH texels of the destination
+constexpr uint32_t kMipBlockW = 32, kMipBlockH = 8;
 __global__ __launch_bounds__(256) void mip_blit_kernel(const uint32_t* __restrict__ src, int sw, int sh, uint32_t* __restrict__ dst, int dw, int dh,
                                                        ShadeTables tab)
 {
-    const int i = (int)(blockIdx.x * 32u + (threadIdx.x & 31u)), j = (int)(blockIdx.y * 8u + (threadIdx.x >> 5));
+    static_assert(kMipBlockW * kMipBlockH == 256, "launch bound of mip_blit_kernel");
+    const int i = (int)(blockIdx.x * kMipBlockW + (threadIdx.x % kMipBlockW)), j = (int)(blockIdx.y * kMipBlockH + (threadIdx.x / kMipBlockW));
     if (i >= dw || j >= dh) return;
     const float sx = (float)sw / (float)dw, sy = (float)sh / (float)dh;
     const float u = ((float)i + 0.5f) * sx - 0.5f, v = ((float)j + 0.5f) * sy - 0.5f;
@@ -1334,15 +1243,6 @@ __global__ __launch_bounds__(256) void count_flags_kernel(const uint32_t* __rest
     if (m && lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(total, (unsigned long long)__popcll(m));
 }
 
-// number of (view, cluster) pairs the cluster test skips (instrumentation, not on the timed path)
-__global__ __launch_bounds__(256) void count_culled_clusters_kernel(ClusterCull cull, FrameGeom g, uint32_t n_clusters, uint32_t n_views, unsigned long long* __restrict__ total)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool c = i < n_clusters * n_views && cluster_is_invisible(cull.clusters[i % n_clusters], cull.views[i / n_clusters], g);
-    const uint64_t m = __ballot(c);
-    if (m && lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(total, (unsigned long long)__popcll(m));
-}
-
 // =================================================================================================
 // host launchers
 // =================================================================================================
@@ -1362,15 +1262,6 @@ void launch_begin_pass(hipStream_t st, uint64_t* vis, size_t n, void* zero16, si
                                               (uint4*)zero16, zero_bytes / 16, (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
 }
 
-void launch_begin_pass_dirty(hipStream_t st, uint64_t* vis, const FrameGeom& g, uint32_t view0, uint32_t n_views, const DirtyMap& dirty,
-                             void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes)
-{
-    const uint32_t n_blocks = (uint32_t)(dirty.nbx * dirty.nby) * n_views;
-    const uint32_t blocks = std::min<uint32_t>(std::max<uint32_t>(n_blocks, 1u), 256u * 16u);
-    begin_pass_dirty_kernel<<<blocks, 256, 0, st>>>((unsigned long long*)vis, g.rw, g.rh, g.samples, view0, n_views, dirty,
-                                                    (uint4*)zero16, zero_bytes / 16, (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
-}
-
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
                    int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out)
 {
@@ -1378,85 +1269,54 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
     vertex_kernel<<<dim3(div_up(n, 256), n_views), 256, 0, st>>>(px, py, pz, n, views, W, H, out, debug_out, (float4*)clip_out);
 }
 
-void launch_pack_positions(hipStream_t st, const void* aos, uint32_t n, void* pos4)
-{
-    if (!n) return;
-    pack_positions_kernel<<<div_up(n, 256), 256, 0, st>>>((const float4*)aos, n, (float4*)pos4);
-}
+// workgroups of the kernels that walk the pending list in chunks: enough to fill the chip when the list is long, few
+// enough to cost next to nothing when it is empty
+static inline uint32_t chunk_grid(const BinBuffers& b) { return std::min<uint32_t>(std::max<uint32_t>(b.n_blocks, 1u), 1024u); }
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
-                  const BinBuffers& b, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between,
-                  const void* pos4, const ViewXform* views, const DirtyMap& dirty, bool bin, const ClusterCull& cull, const ClipList& clip)
+                  const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between)
 {
     if (!n_tris || !n_views) return;
-    const dim3 grid(b.n_blocks, n_views);
-    if (pos4) {
-        if (g.samples == 1) geometry_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty, cull, clip);
-        else geometry_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, (const float4*)pos4, views, dirty, cull, clip);
-    } else if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
-    else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0);
+    const dim3 grid(div_up(n_tris, kBlockTris), n_views);
+    if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0);
+    else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0);
     if (between) (void)hipEventRecord(between, st);
-    if (!bin) return;
-    if (g.samples == 1) bin_kernel<1><<<grid, 256, 0, st>>>(idx, sp, g, b);
-    else bin_kernel<4><<<grid, 256, 0, st>>>(idx, sp, g, b);
+    const dim3 bin_grid(chunk_grid(b), n_views);
+    if (g.samples == 1) bin_kernel<1><<<bin_grid, 256, 0, st>>>(idx, sp, g, b);
+    else bin_kernel<4><<<bin_grid, 256, 0, st>>>(idx, sp, g, b);
 }
 
-void launch_sparse_tail(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                        uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty, uint32_t* host_counters)
+void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const float* px, const float* py, const float* pz,
+                      const ViewXform* views, const FrameGeom& g, const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0)
 {
-    // a few waves per CU; the lists of one pass are dealt out round robin
-    const uint32_t slices = std::max<uint32_t>(b.n_blocks * n_views, 1u);
-    const uint32_t blocks = std::min<uint32_t>((slices + 3u) / 4u, 1024u);
-    if (g.samples == 1) sparse_tail_kernel<1><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
-    else sparse_tail_kernel<4><<<blocks, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, view0, n_views, dirty, host_counters);
-}
-
-void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* pos4, const float* px, const float* py, const float* pz,
-                      const ScreenPlanes& sp, uint32_t n_views, const ViewXform* views, const FrameGeom& g,
-                      const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0, const DirtyMap& dirty, uint32_t* host_counters)
-{
-    if (!pos4 && n_tris && n_views) clip_scan_kernel<<<1024, 256, 0, st>>>(idx, n_tris, n_views, sp, clip, b.counters);
-    // the list is short in any ordinary frame; two thousand waves share the pieces of a long one
-    if (g.samples == 1) near_clip_kernel<1><<<512, 256, 0, st>>>(idx, n_tris, (const float4*)pos4, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, view0, dirty, host_counters);
-    else near_clip_kernel<4><<<512, 256, 0, st>>>(idx, n_tris, (const float4*)pos4, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, view0, dirty, host_counters);
-}
-
-void launch_count_culled_clusters(hipStream_t st, const ClusterCull& cull, const FrameGeom& g, uint32_t n_clusters, uint32_t n_views, uint64_t* total)
-{
-    if (!n_clusters || !n_views) return;
-    count_culled_clusters_kernel<<<div_up((uint64_t)n_clusters * n_views, 256), 256, 0, st>>>(cull, g, n_clusters, n_views, (unsigned long long*)total);
+    if (!n_tris) return;
+    // the list is empty in any ordinary frame; five hundred waves share the pieces of a long one
+    if (g.samples == 1) near_clip_kernel<1><<<128, 256, 0, st>>>(idx, n_tris, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, view0);
+    else near_clip_kernel<4><<<128, 256, 0, st>>>(idx, n_tris, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, view0);
 }
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters)
 {
-    scan_kernel<<<1, 1024, 0, st>>>(b.count_small, b.count_large, n_entries, b.tile_offset, b.counters, b.block_live, b.n_blocks * n_views, host_counters);
+    scan_kernel<<<1, 1024, 0, st>>>(b.count_small, b.count_large, n_entries, b.tile_offset, b.counters, b.pending_total, n_views, host_counters);
 }
 
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views)
 {
     if (!n_tris || !n_views) return;
-    fill_kernel<<<dim3(b.n_blocks, n_views), 256, 0, st>>>(g, b);
-}
-
-template <int TL2, int S, int TPB>
-static void launch_raster_config(hipStream_t st, dim3 grid, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                                 unsigned long long* v, uint32_t view0, const DirtyMap& dirty)
-{
-    if (dirty.flags) raster_kernel<TL2, S, TPB, true><<<grid, TPB, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0, dirty);
-    else raster_kernel<TL2, S, TPB, false><<<grid, TPB, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0, dirty);
+    fill_kernel<<<dim3(chunk_grid(b), n_views), 256, 0, st>>>(g, b);
 }
 
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                   uint64_t* vis, uint32_t view0, uint32_t n_views, const DirtyMap& dirty, bool half_workgroup)
+                   uint64_t* vis, uint32_t view0, uint32_t n_views, bool half_workgroup)
 {
     if (!n_views) return;
     const dim3 grid((uint32_t)(g.tiles_x * g.tiles_y), n_views);
     unsigned long long* v = (unsigned long long*)vis;
-    if (g.samples == 1 && g.tile_log2 == 6) launch_raster_config<6, 1, 1024>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
-    else if (g.samples == 1 && g.tile_log2 == 5) launch_raster_config<5, 1, 256>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
-    else if (g.samples == 4 && g.tile_log2 == 5 && half_workgroup) launch_raster_config<5, 4, 512>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
-    else if (g.samples == 4 && g.tile_log2 == 5) launch_raster_config<5, 4, 1024>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
-    else if (g.samples == 4 && g.tile_log2 == 4) launch_raster_config<4, 4, 256>(st, grid, idx, n_tris, sp, g, b, v, view0, dirty);
+    if (g.samples == 1 && g.tile_log2 == 6) raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    else if (g.samples == 1 && g.tile_log2 == 5) raster_kernel<5, 1, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    else if (g.samples == 4 && g.tile_log2 == 5 && half_workgroup) raster_kernel<5, 4, 512><<<grid, 512, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    else if (g.samples == 4 && g.tile_log2 == 5) raster_kernel<5, 4, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    else if (g.samples == 4 && g.tile_log2 == 4) raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
 }
 
 uint32_t setup_block_triangles() { return kBlockTris; }
@@ -1471,34 +1331,25 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
 {
     if (!f.n_views) return;
     FragParams p;
-    p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.screen = f.screen; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
+    p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
     p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness;
-    p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.dirty = f.dirty;
-    const dim3 grid(div_up((uint32_t)f.g.rw, 32), div_up((uint32_t)f.g.rh, 8), f.n_views), block(32, 8);
-    const bool dirty = f.dirty.flags != nullptr;   // the grid is the dirty map's block grid
-    p.max_aniso = f.max_anisotropy;
-    if (f.max_anisotropy > 1.0f && dirty && f.exact_vertices) {   // the anisotropic variant comes with the other two
-        if (f.g.samples == 1) fragment_kernel<1, true, true, true><<<grid, block, 0, st>>>(p);
-        else fragment_kernel<4, true, true, true><<<grid, block, 0, st>>>(p);
-        return;
-    }
+    p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0;
+    const dim3 grid(div_up((uint32_t)f.g.rw, kFragBlockW), div_up((uint32_t)f.g.rh, kFragBlockH), f.n_views), block(kFragBlockW, kFragBlockH);
+    // the anisotropic footprint is compiled in only when a bound sampler asks for it
+    const bool aniso = f.albedo.max_aniso > 1.0f || f.metallic.max_aniso > 1.0f || f.roughness.max_aniso > 1.0f;
     if (f.g.samples == 1) {
-        if (dirty && f.exact_vertices) fragment_kernel<1, true, true><<<grid, block, 0, st>>>(p);
-        else if (dirty) fragment_kernel<1, true, false><<<grid, block, 0, st>>>(p);
-        else if (f.exact_vertices) fragment_kernel<1, false, true><<<grid, block, 0, st>>>(p);
-        else fragment_kernel<1><<<grid, block, 0, st>>>(p);
+        if (aniso) fragment_kernel<1, true><<<grid, block, 0, st>>>(p);
+        else fragment_kernel<1, false><<<grid, block, 0, st>>>(p);
     } else {
-        if (dirty && f.exact_vertices) fragment_kernel<4, true, true><<<grid, block, 0, st>>>(p);
-        else if (dirty) fragment_kernel<4, true, false><<<grid, block, 0, st>>>(p);
-        else if (f.exact_vertices) fragment_kernel<4, false, true><<<grid, block, 0, st>>>(p);
-        else fragment_kernel<4><<<grid, block, 0, st>>>(p);
+        if (aniso) fragment_kernel<4, true><<<grid, block, 0, st>>>(p);
+        else fragment_kernel<4, false><<<grid, block, 0, st>>>(p);
     }
 }
 
 void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh)
 {
     ShadeTables tab; tab.decode = decode; tab.thresh = thresh;
-    mip_blit_kernel<<<dim3(div_up((uint32_t)dw, 32), div_up((uint32_t)dh, 8)), 256, 0, st>>>(src, sw, sh, dst, dw, dh, tab);
+    mip_blit_kernel<<<dim3(div_up((uint32_t)dw, kMipBlockW), div_up((uint32_t)dh, kMipBlockH)), kMipBlockW * kMipBlockH, 0, st>>>(src, sw, sh, dst, dw, dh, tab);
 }
 
 void launch_split_vis(hipStream_t st, const uint64_t* vis, size_t n, float* depth, uint32_t* tri)

@@ -50,8 +50,7 @@ class Rect(C.Structure):
 
 class DrawStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("vertices", "triangles", "triangles_binned", "tile_refs", "triangles_unprojectable",
-                                           "shaded_pixels", "visible_triangles", "pixels", "triangles_direct", "clusters_culled", "cull_violations",
-                                           "triangles_clipped")]
+                                           "shaded_pixels", "visible_triangles", "pixels", "triangles_direct", "triangles_clipped")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -65,6 +64,26 @@ class StageTimes(C.Structure):
 
 
 _lib = None
+
+# maxAnisotropy of the sampler create_texture / create_texture_from_file make when none is passed.  None: the library's
+# own default, which is the reference's (16, src/texture.cpp:255-256).  A process that wants plain trilinear filtering
+# everywhere sets it to 1.0.
+DEFAULT_MAX_ANISOTROPY = None
+
+
+def default_sampler(max_anisotropy: float | None = None) -> "SamplerDesc":
+    """The sampler of src/texture.cpp:246-263, optionally with another maxAnisotropy (<= 1: isotropic)."""
+    s = SamplerDesc()
+    load_library().sr_sampler_default(C.byref(s))
+    if max_anisotropy is not None:
+        s.max_anisotropy = float(max_anisotropy)
+    return s
+
+
+def _sampler_arg(sampler):
+    if sampler is None and DEFAULT_MAX_ANISOTROPY is not None:
+        sampler = default_sampler(DEFAULT_MAX_ANISOTROPY)
+    return C.byref(sampler) if sampler is not None else None
 
 
 def load_library():
@@ -224,8 +243,7 @@ def create_texture(device: Device, data: np.ndarray, tex_width: int | None = Non
     if d.size != tex_width * tex_height * 4:
         raise ValueError("data must hold width*height RGBA8 texels")
     h = C.c_void_p()
-    _check(device._lib.sr_texture_create_rgba8_srgb(device._h, d.ctypes.data, tex_width, tex_height,
-                                                    C.byref(sampler) if sampler is not None else None, C.byref(h)),
+    _check(device._lib.sr_texture_create_rgba8_srgb(device._h, d.ctypes.data, tex_width, tex_height, _sampler_arg(sampler), C.byref(h)),
            "sr_texture_create_rgba8_srgb")
     return Texture(device, h, tex_width, tex_height)
 
@@ -249,8 +267,7 @@ def read_image(path: str) -> np.ndarray:
 def create_texture_from_file(device: Device, texture_path: str, sampler: SamplerDesc | None = None) -> Texture:
     """src/texture.hpp:20 / src/texture.cpp:273-291."""
     h = C.c_void_p()
-    _check(device._lib.sr_texture_create_from_file(device._h, os.fsencode(texture_path), C.byref(sampler) if sampler is not None else None,
-                                                   C.byref(h)), "sr_texture_create_from_file")
+    _check(device._lib.sr_texture_create_from_file(device._h, os.fsencode(texture_path), _sampler_arg(sampler), C.byref(h)), "sr_texture_create_from_file")
     w, ht = C.c_int(), C.c_int()
     _check(device._lib.sr_texture_size(h, C.byref(w), C.byref(ht)), "sr_texture_size")
     return Texture(device, h, w.value, ht.value)
