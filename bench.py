@@ -241,6 +241,7 @@ def main():
                     help="views: every rank draws its own cameras of the workload (weak scaling, no collective); "
                          "sortfirst: one 7680x4320 frame split into bands over the ranks, bands sent to rank 0 (strong scaling)")
     ap.add_argument("--max-anisotropy", type=float, default=1.0, help="maxAnisotropy of the samplers of the timed run (1: trilinear; the reference's own sampler has 16)")
+    ap.add_argument("--lib", default=None, help="time another build of the library (tools/exp_build.py) instead of the shipped one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -252,6 +253,8 @@ def main():
         import torch.distributed as dist
 
     import softraster as sr
+    if args.lib:
+        sr.LIB_PATH = os.path.abspath(args.lib)
     if args.mode == "sortfirst":
         return sort_first(args, sr, rank, local_rank, world)
     workload = args.workload or ("c3_4k_10Mtri" if world == 1 else "c5_50Mtri_views")

@@ -16,7 +16,7 @@ def pytest_configure(config):
 # Within test_gpu_parity.py the tests of the basic draw paths are run before those of the grow-and-repeat,
 # hash-overflow, pass-splitting, target-reuse and file-loading paths: the suite is run with -x, and a failure in
 # one of the special paths should not hide the results of the basic ones.
-RUN_AFTER_THE_BASIC_PARITY_TESTS = ("test_target_is_reused_across_different_draws", "test_mesh_and_textures_destroyed_before_the_read_back",
+RUN_AFTER_THE_BASIC_PARITY_TESTS = ("test_target_is_reused_across_different_draws", "test_mesh_and_textures_destroyed_before_the_read_back", "test_lean_draws_and_their_fallback",
                                     "test_model_and_textures_from_files", "test_tile_reference_list_grows_and_the_draw_is_repeated",
                                     "test_more_distinct_tiles_than_a_binning_block_can_hash", "test_view_batch_split_into_passes", "test_near_plane_clipper",
                                     "test_fragments_exactly_on_the_far_plane")

@@ -19,6 +19,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "vulkan-renderer_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
+# HIPEMU_EXTRA_FLAGS="-DSR_TRIS_PER_THREAD=2 ...": the emulation build of a tuning variant (tools/exp_build.py), kept apart from the default one
+EXTRA_FLAGS = os.environ.get("HIPEMU_EXTRA_FLAGS", "").split()
+if EXTRA_FLAGS:
+    BUILD = os.path.join(HERE, "_build", "variant_" + "".join(c if c.isalnum() else "_" for c in "".join(EXTRA_FLAGS)))
 LIB = os.path.join(BUILD, "libsoftraster_emu.so")
 SOURCES = ("sr_kernels.hip", "sr_api.hip")
 HEADERS = ("sr_device.h", "sr_launch.h", "sr_assets.h", "sr_assets.cpp", "sr_jpeg.cpp")
@@ -26,7 +30,7 @@ HEADERS = ("sr_device.h", "sr_launch.h", "sr_assets.h", "sr_assets.cpp", "sr_jpe
 _LAUNCH = re.compile(r"([A-Za-z_]\w*(?:<[^<>;()]*>)?)\s*<<<(.*?)>>>\s*\(")
 
 
-_BOUNDS = re.compile(r"__launch_bounds__\((\d+)\)\s+void\s+([A-Za-z_]\w*)")
+_BOUNDS = re.compile(r"__launch_bounds__\((\d+)\)\s+(?:[A-Z_]+\s+)?void\s+([A-Za-z_]\w*)")
 
 
 def translate(text: str) -> str:
@@ -63,7 +67,7 @@ def build(force: bool = False, opt: str = "-O1") -> str:
         units.append(dst)
     cmd = ["g++", "-std=c++17", opt, "-g", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden",
            "-Wl,-Bsymbolic", "-Wno-unknown-pragmas", "-U_FORTIFY_SOURCE",
-           "-I", HERE, "-I", CSRC, *units, os.path.join(CSRC, "sr_assets.cpp"), os.path.join(CSRC, "sr_jpeg.cpp"), os.path.join(HERE, "hipemu.cpp"), "-lz", "-o", LIB]
+           "-I", HERE, "-I", CSRC, *EXTRA_FLAGS, *units, os.path.join(CSRC, "sr_assets.cpp"), os.path.join(CSRC, "sr_jpeg.cpp"), os.path.join(HERE, "hipemu.cpp"), "-lz", "-o", LIB]
     subprocess.check_call(cmd)
     return LIB
 

@@ -151,34 +151,36 @@ template <class T> inline T from_bits(uint64_t b) { T v; std::memcpy(&v, &b, siz
 #define gridDim (::hipemu::g_grid_dim)
 
 // ---- device intrinsics -----------------------------------------------------------------------------
-#define HIPEMU_SITE __builtin_extract_return_addr(__builtin_return_address(0))
+// A call site of a wave-wide operation is identified by its source line, not by its address: the host compiler clones
+// code (loop unrolling, jump threading on a lane-dependent condition), so that lanes at the same point of the kernel
+// can sit at different addresses of the same source-level call.
+#define HIPEMU_SITE_OF_LINE(line) reinterpret_cast<const void*>(static_cast<uintptr_t>(line))
 
 static inline void __syncthreads() { ::hipemu::barrier(); }
 static inline void __threadfence() {}   // one work-item runs at a time: every store is visible at once
 
-__attribute__((noinline)) static uint64_t hipemu_ballot(bool pred) { return ::hipemu::wave_exchange(0, pred, HIPEMU_SITE).pred_mask; }
-#define __ballot(pred) hipemu_ballot((pred) != 0)
+__attribute__((noinline)) static uint64_t hipemu_ballot(bool pred, int line) { return ::hipemu::wave_exchange(0, pred, HIPEMU_SITE_OF_LINE(line)).pred_mask; }
+#define __ballot(pred) hipemu_ballot((pred) != 0, __LINE__)
 
-// reads lane `src` of the exchange; the (not inlined) helper's return address identifies the call
-// site in the kernel because every wrapper around it is force-inlined
+// reads lane `src` of the exchange; `line` is the source line of the __shfl* call in the kernel
 template <class T>
-__attribute__((noinline)) static T hipemu_shfl_abs(T v, int src)
+__attribute__((noinline)) static T hipemu_shfl_abs(T v, int src, int line)
 {
-    const ::hipemu::WaveResult& r = ::hipemu::wave_exchange(::hipemu::to_bits(v), false, HIPEMU_SITE);
+    const ::hipemu::WaveResult& r = ::hipemu::wave_exchange(::hipemu::to_bits(v), false, HIPEMU_SITE_OF_LINE(line));
     const int s = src & 63;
     if (!((r.group_mask >> s) & 1ull)) { ::hipemu::note_error("__shfl reads a lane that is not active at the call"); return T(); }
     return ::hipemu::from_bits<T>(r.value[s]);
 }
-template <class T> __attribute__((always_inline)) static inline T __shfl(T v, int src) { return hipemu_shfl_abs(v, src); }
-template <class T> __attribute__((always_inline)) static inline T __shfl_down(T v, unsigned delta)
+template <class T> __attribute__((always_inline)) static inline T __shfl(T v, int src, int line = __builtin_LINE()) { return hipemu_shfl_abs(v, src, line); }
+template <class T> __attribute__((always_inline)) static inline T __shfl_down(T v, unsigned delta, int line = __builtin_LINE())
 {
     const int me = (int)::hipemu::cur->lane;
-    return hipemu_shfl_abs(v, me + (int)delta < 64 ? me + (int)delta : me);
+    return hipemu_shfl_abs(v, me + (int)delta < 64 ? me + (int)delta : me, line);
 }
-template <class T> __attribute__((always_inline)) static inline T __shfl_up(T v, unsigned delta)
+template <class T> __attribute__((always_inline)) static inline T __shfl_up(T v, unsigned delta, int line = __builtin_LINE())
 {
     const int me = (int)::hipemu::cur->lane;
-    return hipemu_shfl_abs(v, me >= (int)delta ? me - (int)delta : me);
+    return hipemu_shfl_abs(v, me >= (int)delta ? me - (int)delta : me, line);
 }
 
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }

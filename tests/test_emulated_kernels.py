@@ -39,9 +39,9 @@ def build_emulation_library():
     build_emu.build()   # once, before child processes race to build it
 
 
-# device-level knobs under which every frame must stay the same: smaller tiles, the 512-work-item form of the 4-sample
-# tile kernel, a tile reference list that overflows on every first frame, a scratch budget that splits batches into passes
-KNOBS = [dict(SR_TILE_LOG2="5"), dict(SR_RASTER_HALF="1"), dict(SR_REF_CAPACITY="16"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4")]
+# device-level knobs under which every frame must stay the same: smaller tiles, a tile reference list that overflows on
+# every first frame, a scratch budget that splits batches into passes
+KNOBS = [dict(SR_TILE_LOG2="5"), dict(SR_REF_CAPACITY="16"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4")]
 _child_runs = {}
 
 
@@ -72,8 +72,7 @@ def test_gpu_parity_suite_on_emulated_kernels():
 
 
 def test_device_knobs_give_the_same_frames():
-    """Tile size, workgroup size of the 4-sample tile kernel, initial size of the tile reference list and the scratch
-    budget are per-device settings (environment variables read by sr_device_create) that must not change a frame:
+    """Tile size, initial size of the tile reference list and the scratch budget are per-device settings (environment variables read by sr_device_create) that must not change a frame:
     the whole parity suite under each of them."""
     for r in child_runs()["knobs"]:
         finish(r)
@@ -162,7 +161,7 @@ def test_scene_driver_under_address_and_ub_sanitizers():
     exe = build_emu.build_sanitized()
     env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     runs = [(k, subprocess.Popen([exe], env=dict(env, **k), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-            for k in ({}, dict(SR_TILE_LOG2="5", SR_RASTER_HALF="1"), dict(SR_REF_CAPACITY="16", SR_SCRATCH_MIB="1"))]
+            for k in ({}, dict(SR_TILE_LOG2="5"), dict(SR_REF_CAPACITY="16", SR_SCRATCH_MIB="1"))]
     for k, proc in runs:
         out, _ = proc.communicate(timeout=1200)
         assert proc.returncode == 0 and "ok: 32 draws" in out and "runtime error" not in out and "AddressSanitizer" not in out, f"knobs {k}:\n{out[-3000:]}"

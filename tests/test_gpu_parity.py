@@ -245,6 +245,47 @@ def test_vertex_near_the_eye_plane_and_far_off_frame(sr, oracle, device, seed):
     fuzz_parity.check_seed(seed, sr, oracle, device, util)
 
 
+def test_lean_draws_and_their_fallback(sr, oracle):
+    """A draw that follows one which left nothing for the tile lists and the clipper is issued without those kernels;
+    if it turns out to need them after all, it is issued again in full before anything of it can be observed.  One
+    target, one mesh, a camera that jumps: far (micro-triangles only) twice, close (triangles of a dozen pixels), far
+    three times, then almost on the surface (vertices behind the eye: the clipper is needed).  Every frame and its
+    counters equal the oracle's."""
+    W, H = 192, 108
+    verts, idx = sr.scene.uv_sphere(200, 150)
+    images = sr.scene.material_textures(32)
+    far, close, touching = (2.0, 2.0, 2.0), (0.65, 0.65, 0.63), (0.585, 0.58, 0.575)
+    dev = sr.Device(0)
+    try:
+        mesh = sr.create_mesh_from_data(dev, verts, idx)
+        tex = [sr.create_texture(dev, im) for im in images]
+        tgt = sr.RenderTarget(dev, W, H)
+        seen = []
+        import math
+        for eye in (far, far, close, far, far, far, touching, far):
+            ubo = sr.scene.default_camera_ubo(W, H, eye=eye)
+            if eye is touching:     # just above the surface, looking along it: part of the sphere lies behind the eye plane
+                e = np.array([0.0, -1.02, 0.0])
+                ubo = sr.scene.make_ubo(np.eye(4, dtype=np.float32), sr.scene.look_at(e, (0.9, -0.9, 0.1), (0.0, 0.0, 1.0)),
+                                        sr.scene.perspective(math.radians(45.0), W / H, 0.002, 10.0), e)   # (a near plane closer than a triangle is wide)
+            sr.draw(dev, tgt, mesh, ubo, tex)
+            got = {"tri": tgt.read_triangle_ids(0), "depth": tgt.read_depth(0), "bgra": tgt.read_color(0)}
+            st = tgt.stats()
+            ref = oracle.draw(ubo, verts, idx, images, W, H)
+            _check_view(got, ref)
+            assert st["triangles_clipped"] == ref["stats"]["tris_clipped"] and st["triangles_unprojectable"] == 0
+            seen.append((st["triangles_binned"], st["triangles_clipped"]))
+        assert seen[0] == seen[1] == (0, 0), seen          # the far camera leaves nothing pending: draw 2 was lean
+        assert seen[2][0] > 0 and seen[6][1] > 0, seen     # draws 3 and 7 were issued lean and needed the full pipeline
+        assert seen[5] == (0, 0) and seen[7][1] == 0, seen
+        tgt.destroy()
+        mesh.destroy()
+        for t in tex:
+            t.destroy()
+    finally:
+        dev.close()
+
+
 def test_model_and_textures_from_files(sr, oracle, device, tmp_path):
     """Model::load and create_texture_from_file: a glTF file with two meshes and PNG maps, written here,
     drawn through the file-taking entry points, equals the oracle's frame of the arrays they were made of."""
@@ -518,35 +559,61 @@ def test_cpp_host_app_matches_python_host(sr, device, tmp_path):
     verts, idx = sr.scene.uv_sphere(48, 32)
     images = [sr.scene.albedo_pattern(2048), sr.scene.constant_rgba(64, 64, (128, 128, 255, 255)),
               sr.scene.gray_map(2048, 2048, 0, 254), sr.scene.gray_map(2048, 2048, 72, 255)]
-    got = util.gpu_render(sr, device, verts, idx, images, sr.scene.default_camera_ubo(320, 240), 320, 240)[0]
+    sr.DEFAULT_MAX_ANISOTROPY = None     # the application creates its textures with the library's default sampler (the reference's: maxAnisotropy 16)
+    try:
+        got = util.gpu_render(sr, device, verts, idx, images, sr.scene.default_camera_ubo(320, 240), 320, 240)[0]
+    finally:
+        sr.DEFAULT_MAX_ANISOTROPY = 1.0
     frac, worst = util.color_match_fraction(rgb, got["bgra"][..., [2, 1, 0]], 2)
     assert frac >= 0.995, (frac, worst)
 
 
 def test_colour_bound_to_caller_memory(sr, oracle, device):
-    """sr_target_bind_color: the frame lands in a torch tensor (what the sort-first composite hands to RCCL)."""
+    """sr_target_bind_color: the bands of a frame land in caller-owned device memory (what the sort-first composite
+    hands to RCCL) and composite to the single-target frame bit for bit.  The memory comes from the HIP runtime the
+    library itself uses; when torch sees the GPU too, the same is done once more into torch tensors."""
+    import ctypes
     import os
     if os.environ.get("SR_TEST_EMULATED") == "1":
-        pytest.skip("needs a torch tensor in GPU memory; not part of the CPU emulation run")
-    import torch
+        pytest.skip("needs caller-owned GPU memory; not part of the CPU emulation run")
     from softraster import distributed as d
+    hip = ctypes.CDLL("libamdhip64.so.7")   # already mapped by the library: the same runtime, the same context
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    W, H = 256, 192
     verts, idx = sr.scene.uv_sphere(32, 24)
     images = sr.scene.material_textures(64)
-    ubo = sr.scene.default_camera_ubo(256, 192)
+    ubo = sr.scene.default_camera_ubo(W, H)
     mesh = sr.create_mesh_from_data(device, verts, idx)
     tex = [sr.create_texture(device, im) for im in images]
-    bands = d.split_bands(256, 192, 3)
-    parts = []
-    for band in bands:
-        t, tgt = d.render_band_to_tensor(sr, device, mesh, tex, ubo, 256, 192, band)
-        parts.append(t.cpu().numpy())
-        tgt.destroy()
-    frame = np.concatenate(parts, axis=0)
-    ref = oracle.draw(ubo, verts, idx, images, 256, 192)
-    frac, worst = util.color_match_fraction(frame, ref["bgra"], 1)
-    assert frac >= 0.999, (frac, worst)
-    full = util.gpu_render(sr, device, verts, idx, images, ubo, 256, 192, textures=tex)[0]
-    assert np.array_equal(frame, full["bgra"])       # bands composite to the single-target frame bit for bit
-    for t in tex:
-        t.destroy()
-    mesh.destroy()
+    bands = d.split_bands(W, H, 3)
+    try:
+        frame_mem = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(frame_mem), W * H * 4) == 0
+        for (x, y, w, h) in bands:       # every band renders straight into its rows of the one frame
+            tgt = sr.RenderTarget(device, W, H, rect=(x, y, w, h))
+            tgt.bind_color(frame_mem.value + y * W * 4)
+            sr.draw(device, tgt, mesh, ubo, tex)
+            device.synchronize()
+            tgt.destroy()
+        frame = np.empty((H, W, 4), np.uint8)
+        assert hip.hipMemcpy(frame.ctypes.data, frame_mem, frame.nbytes, 2) == 0     # hipMemcpyDeviceToHost
+        assert hip.hipFree(frame_mem) == 0
+        ref = oracle.draw(ubo, verts, idx, images, W, H)
+        frac, worst = util.color_match_fraction(frame, ref["bgra"], 1)
+        assert frac >= 0.999, (frac, worst)
+        full = util.gpu_render(sr, device, verts, idx, images, ubo, W, H, textures=tex)[0]
+        assert np.array_equal(frame, full["bgra"])       # bands composite to the single-target frame bit for bit
+        import torch
+        if torch.cuda.is_available():
+            parts = []
+            for band in bands:
+                t, tgt = d.render_band_to_tensor(sr, device, mesh, tex, ubo, W, H, band)
+                parts.append(t.cpu().numpy())
+                tgt.destroy()
+            assert np.array_equal(np.concatenate(parts, axis=0), full["bgra"])
+    finally:
+        mesh.destroy()
+        for t in tex:
+            t.destroy()

@@ -70,7 +70,6 @@ struct sr_device_t {
     uint64_t ref_capacity = 0;
     size_t scratch_budget = (size_t)16 << 30;
     int tile_log2_override = 0;
-    bool raster_half = false;    // SR_RASTER_HALF=1: the 4-sample tile kernel runs 512 work-items per 32x32 tile (measurement switch)
     bool profiling = false;
     std::vector<hipEvent_t> events;   // kNumStageEvents per pass of the last profiled draw
     size_t events_used = 0;
@@ -114,6 +113,13 @@ struct sr_target_t {
     uint32_t* h_counters = nullptr; void* hd_counters = nullptr; size_t h_counters_cap = 0;   // pinned + mapped, [passes][8], written by the scan kernel of the last draw
     uint64_t capacity_at_draw = 0;
     uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0, clipped = 0;
+    // A frame of nothing but micro-triangles leaves the binning, clipping, scan, fill and tile kernels without work, yet
+    // each costs a launch and a chain of dependent loads (30 us of a 240 us frame).  When the previous draw of this
+    // target (same mesh) left them nothing, the next one is issued without them ("lean"): set-up is followed by the
+    // one-workgroup kernel that reports the counters.  If the counters then say that there was work after all, the
+    // draw is issued again in full before anything of it can be observed (finish_target), like a draw whose tile
+    // reference list overflowed.
+    bool lean = false;
 };
 
 namespace {
@@ -172,15 +178,16 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     if (dev->ref_capacity == 0) dev->ref_capacity = std::max<uint64_t>((uint64_t)m->n_tris * vpp, (uint64_t)1 << 20);
     dev->ref_capacity = std::min<uint64_t>(dev->ref_capacity, 0xFFFFFFFFull);
 
-    const uint32_t bt = setup_block_triangles();
-    const uint32_t n_blocks = std::max((m->n_tris + bt - 1u) / bt, 1u);
+    const uint32_t bt = chunk_triangles(), sbt = setup_block_triangles();
+    const uint32_t n_blocks = std::max((m->n_tris + bt - 1u) / bt, 1u);            // chunks of a view's pending list
+    const uint32_t n_setup_blocks = std::max((m->n_tris + sbt - 1u) / sbt, 1u);
     const uint32_t pending_stride = n_blocks * bt;
     const size_t count_words = (size_t)vpp * n_tiles * 3;
     SR_HIP(dev->screen.ensure((size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex)));
     // layout of the binning state: [count_small | count_large | cursor_large | pending_total per view | counters of this pass]
-    // (zeroed at the start of every pass, padded to 16 bytes) [block_count: written by the binning kernel]
+    // (zeroed at the start of every pass, padded to 16 bytes) [block_count: written by the binning kernel] [block_micro: by set-up]
     const size_t zero_words = (count_words + vpp + kNumPassCounters + 3) & ~(size_t)3;
-    SR_HIP(dev->tile_count.ensure((zero_words + (size_t)vpp * n_blocks) * 4));
+    SR_HIP(dev->tile_count.ensure((zero_words + (size_t)vpp * n_blocks + (size_t)vpp * n_setup_blocks) * 4));
     SR_HIP(dev->pending.ensure((size_t)vpp * pending_stride * 4));
     SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
     SR_HIP(dev->records.ensure((size_t)vpp * n_blocks * setup_block_records() * sizeof(BinRecord)));
@@ -227,6 +234,8 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     b.pending_total = b.count_small + count_words;
     b.counters = b.pending_total + vpp;
     b.block_count = b.count_small + zero_words;
+    b.block_micro = b.block_count + (size_t)vpp * n_blocks;
+    b.n_setup_blocks = m->n_tris ? n_setup_blocks : 0u;   // (an empty mesh launches no set-up block: nothing to sum)
     b.pending = (uint32_t*)dev->pending.ptr;
     b.pending_stride = pending_stride;
     b.n_blocks = n_blocks;
@@ -251,22 +260,29 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, v0, ev ? ev[3] : nullptr);
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, !tg->lean);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
-        // (before the scan kernel, which reports the counters to the host)
-        launch_near_clip(st, m->d_idx, m->n_tris, m->px, m->py, m->pz, d_views, g, clip, b, tg->d_vis, v0);
-        launch_scan(st, b, nv * n_tiles, nv, pass_counters);
-        if (ev) SR_HIP(hipEventRecord(ev[5], st));
-        launch_fill(st, g, b, m->n_tris, nv);
-        if (ev) SR_HIP(hipEventRecord(ev[6], st));
-        launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv, dev->raster_half);
+        if (tg->lean) {
+            launch_scan(st, b, 0, nv, pass_counters);   // nothing to scan: reports the counters of the pass
+            if (ev) { SR_HIP(hipEventRecord(ev[5], st)); SR_HIP(hipEventRecord(ev[6], st)); }
+        } else {
+            // (before the scan kernel, which reports the counters to the host)
+            launch_near_clip(st, m->d_idx, m->n_tris, m->px, m->py, m->pz, d_views, g, clip, b, tg->d_vis, v0);
+            launch_scan(st, b, nv * n_tiles, nv, pass_counters);
+            if (ev) SR_HIP(hipEventRecord(ev[5], st));
+            launch_fill(st, g, b, m->n_tris, nv);
+            if (ev) SR_HIP(hipEventRecord(ev[6], st));
+            launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv);
+        }
         if (ev) SR_HIP(hipEventRecord(ev[7], st));
         FragLaunch f{};
         f.idx = m->d_idx; f.verts_aos = m->d_aos; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv;
+        f.identity_model = true;
+        for (uint32_t v = v0; v < v0 + nv; ++v) f.identity_model = f.identity_model && tg->views[v].model_is_identity != 0.0f;
         launch_fragment(st, f);
         if (ev) SR_HIP(hipEventRecord(ev[8], st));
     }
@@ -282,17 +298,19 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
 {
     SR_HIP(hipStreamSynchronize(dev->stream));
     if (!tg->check_pending) return SR_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0, clipped = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0, clipped = 0, listed = 0;
         for (uint32_t p = 0; p < tg->passes; ++p) {
             const uint32_t* c = tg->h_counters + (size_t)p * kCountersPerPass;
             worst = std::max<uint64_t>(worst, c[0]); total += c[0]; unproj += c[2]; binned += c[3]; micro += c[4];
-            clipped += c[6];
+            listed += c[5]; clipped += c[6];
         }
         tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned; tg->micro = micro; tg->clipped = clipped;
-        if (worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
-        if (attempt == 1) break;
-        dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull);
+        const bool lean_missed = tg->lean && (binned > 0 || listed > 0);    // drawn without the kernels it turned out to need
+        if (!lean_missed && worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
+        if (attempt == 2) break;
+        if (lean_missed) tg->lean = false;
+        else dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull);
         int rc = issue_draw(dev, tg);
         if (rc != SR_OK) return rc;
         SR_HIP(hipStreamSynchronize(dev->stream));
@@ -374,7 +392,6 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* v = std::getenv("SR_REF_CAPACITY")) dev->ref_capacity = (uint64_t)std::max(1, std::atoi(v));   // initial size of the tile reference list (tests: force the grow-and-redraw path)
     if (const char* v = std::getenv("SR_CLIP_CAPACITY")) dev->clip_capacity = (uint32_t)std::max(1, std::atoi(v));   // tests: a full clip list
     if (const char* v = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 20;   // small budgets: many passes per draw
-    if (const char* v = std::getenv("SR_RASTER_HALF")) dev->raster_half = std::atoi(v) != 0;
     *out = dev;
     return SR_OK;
 }
@@ -400,6 +417,11 @@ int sr_device_synchronize(sr_device dev)
     if (!dev) return fail(SR_ERR_INVALID_ARGUMENT, "device is NULL");
     SR_HIP(hipSetDevice(dev->ordinal));
     SR_HIP(hipStreamSynchronize(dev->stream));
+    // idle means: every draw is complete, including those that have to be issued a second time (a tile reference list
+    // that was too small, a lean draw that needed the full pipeline) -- a caller who bound his own colour memory to a
+    // target reads it after this call
+    for (sr_target_t* t : dev->targets)
+        if (t->check_pending) { const int rc = finish_target(dev, t); if (rc != SR_OK) return rc; }
     return SR_OK;
 }
 
@@ -707,6 +729,16 @@ int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_block
             }
     }
     (void)hipGetLastError();
+    {   // lean or full (see sr_target_t::lean): from the counters of this target's previous draw.  They live in pinned
+        // memory the kernels write; that draw may still be in flight, in which case the figures are a frame older --
+        // either way only speed depends on them.
+        bool lean = target->passes > 0 && target->mesh == mesh && target->views.size() == n_views && std::getenv("SR_NO_LEAN") == nullptr;
+        for (uint32_t p = 0; lean && p < target->passes; ++p) {
+            const volatile uint32_t* c = target->h_counters + (size_t)p * kCountersPerPass;
+            lean = c[3] == 0u && c[5] == 0u;
+        }
+        target->lean = lean;
+    }
     target->mesh = mesh; target->mesh_verts = mesh->n_verts; target->mesh_tris = mesh->n_tris;
     for (int k = 0; k < 4; ++k) target->tex[k] = textures[k];
     target->views.resize(n_views);

@@ -206,7 +206,6 @@ enum : uint32_t {
     kCtrRefs = 0,          // total tile references (written by the scan kernel)
     kCtrRefsDropped = 1,   // references that found no room in the list
     kCtrUnprojectable = 2, // triangles that would need clipping and could not be clipped (clip list full, degenerate projection)
-    kCtrMicro = 4,         // micro-triangles resolved by the set-up kernel itself
     kCtrClipListed = 7,    // triangles put on the clip list by set-up (may exceed its capacity)
     kCtrClipped = 8,       // triangles the near-plane clipper cut and drew
     kNumPassCounters = 16,
@@ -227,7 +226,9 @@ struct BinBuffers {
     BinRecord* records;       // [views][chunks][chunk triangles * kMaxSmallTiles]: the binning kernel takes the pending list in chunks,
                               // each chunk owns one segment
     uint32_t* block_count;    // [views][chunks]: records written for each chunk
-    uint32_t n_blocks;        // chunks per view at most (= set-up blocks per view)
+    uint32_t n_blocks;        // chunks per view at most
+    uint32_t* block_micro;    // [views][n_setup_blocks]: micro-triangles each set-up block resolved itself (instrumentation)
+    uint32_t n_setup_blocks;  // set-up blocks per view
     uint32_t* counters;       // [kNumPassCounters]
 };
 

@@ -16,6 +16,7 @@ struct FragLaunch {
     const float* decode;
     const float* thresh;
     uint32_t view0, n_views;
+    bool identity_model;       // the model matrix of every one of these views is the identity
 };
 
 void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz);
@@ -26,7 +27,7 @@ void launch_begin_pass(hipStream_t st, uint64_t* vis, size_t n, void* zero16, si
 // triangle set-up (micro-triangles resolved, clip list and pending lists filled) followed by the binning of the pending lists
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0,
-                  hipEvent_t between /* recorded between set-up and binning, may be null */);
+                  hipEvent_t between /* recorded between set-up and binning, may be null */, bool bin = true /* false: set-up only */);
 // near-plane clipping of the triangles set-up listed: cuts them and resolves the pieces into the visibility buffer.
 // Runs after launch_setup and before launch_scan (which reports the counters to the host).
 void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const float* px, const float* py, const float* pz,
@@ -34,10 +35,10 @@ void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, cons
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters);
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views);
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                   uint64_t* vis, uint32_t view0, uint32_t n_views,
-                   bool half_workgroup = false /* 4-sample 32x32 tiles with 512 work-items instead of 1024 (no register spills) */);
+                   uint64_t* vis, uint32_t view0, uint32_t n_views);
 bool raster_config_supported(int samples, int tile_log2);
-uint32_t setup_block_triangles();   // triangles handled by one set-up block = triangles of one chunk of the pending list
+uint32_t setup_block_triangles();   // triangles handled by one set-up block
+uint32_t chunk_triangles();         // triangles of one chunk of the pending list (what one turn of a binning workgroup takes)
 uint32_t setup_block_records();     // size of the record segment one chunk owns
 void launch_fragment(hipStream_t st, const FragLaunch& f);
 void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh);
