@@ -9,16 +9,22 @@ import bench
 tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = "gpurun_out/profile_round"
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True)[0]
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: take the most recent run's only"""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+stats = newest(root + "/trace/**/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_c3_kernel_stats.csv")
 line = [l for l in open(root + "/trace.log") if l.startswith("{")][-1]
 open(f"profiles/{tag}_c3_bench_under_rocprof.json", "w").write(line)
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
-    for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
+    for f in [newest(path + "/**/*counter_collection.csv")]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sr::", "").split("<")[0]].append(float(r["Counter_Value"]))
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sr::", "")
+                if name.startswith("fragment_kernel") and "true, " in name.split("<")[1]:
+                    continue    # the benchmark's second figure (16x anisotropic sampler): not the launch the roofline line is about
+                acc[name.split("<")[0]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 fetch, write = per_kernel(root + "/fetch", "FETCH_SIZE"), per_kernel(root + "/write", "WRITE_SIZE")
 names = {"begin_pass_kernel": "clear", "vertex_kernel": "vertex", "setup_kernel": "setup", "bin_kernel": "bin", "scan_kernel": "scan",

@@ -102,6 +102,7 @@ struct sr_target_t {
     uint64_t* d_vis = nullptr;
     uint32_t* d_color_own = nullptr;
     uint32_t* d_color = nullptr;
+    BlockFlags flags{nullptr, 0, 0};   // which blocks of the visibility buffer hold anything (sr_device.h); all set at creation
     // the last draw, kept so that it can be re-issued if the reference list was too small; mesh and textures are
     // referenced only while check_pending is set (destroying one of them resolves the draw first)
     bool drawn = false, check_pending = false;
@@ -254,8 +255,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         const ViewXform* d_views = (const ViewXform*)dev->views.ptr + v0;
         hipEvent_t* ev = dev->profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
         if (ev) SR_HIP(hipEventRecord(ev[0], st));
-        launch_begin_pass(st, tg->d_vis + (size_t)v0 * g.rw * g.rh * g.samples, (size_t)nv * g.rw * g.rh * g.samples, b.count_small, zero_words * 4,
-                          sg.d, dev->views.ptr, pass == 0 ? view_bytes : 0);
+        launch_begin_pass(st, tg->d_vis, tg->flags, g, v0, nv, b.count_small, zero_words * 4, sg.d, dev->views.ptr, pass == 0 ? view_bytes : 0);
         if (pass == 0) { SR_HIP(hipEventRecord(sg.ev, st)); sg.in_flight = true; }
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
@@ -280,7 +280,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         FragLaunch f{};
         f.idx = m->d_idx; f.verts_aos = m->d_aos; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
-        f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv;
+        f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv; f.flags = tg->flags;
         f.identity_model = true;
         for (uint32_t v = v0; v < v0 + nv; ++v) f.identity_model = f.identity_model && tg->views[v].model_is_identity != 0.0f;
         launch_fragment(st, f);
@@ -644,10 +644,18 @@ int sr_target_create(sr_device dev, int width, int height, int samples, uint32_t
     if (e == hipSuccess) e = hipMalloc((void**)&t->d_color_own, px * 4 * n_views);
     if (e != hipSuccess) { (void)hipFree(t->d_vis); delete t; SR_HIP(e); }
     t->d_color = t->d_color_own;
+    // every block of the visibility buffer counts as holding something until a first draw has cleared it
+    t->flags.nbx = (g.rw + (int)kFlagBlockW - 1) / (int)kFlagBlockW;
+    t->flags.nby = (g.rh + (int)kFlagBlockH - 1) / (int)kFlagBlockH;
+    const size_t flag_bytes = (size_t)n_views * t->flags.nbx * t->flags.nby * 4;
+    e = hipMalloc((void**)&t->flags.flags, flag_bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(t->flags.flags, 0x01, flag_bytes, dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    if (e != hipSuccess) { (void)hipFree(t->d_vis); (void)hipFree(t->d_color_own); (void)hipFree(t->flags.flags); delete t; SR_HIP(e); }
     // room for the counters of a one-pass draw, so that such a draw allocates nothing here
     e = hipHostMalloc((void**)&t->h_counters, (size_t)kCountersPerPass * 4, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer(&t->hd_counters, t->h_counters, 0);
-    if (e != hipSuccess) { (void)hipFree(t->d_vis); (void)hipFree(t->d_color_own); if (t->h_counters) (void)hipHostFree(t->h_counters); delete t; SR_HIP(e); }
+    if (e != hipSuccess) { (void)hipFree(t->d_vis); (void)hipFree(t->d_color_own); (void)hipFree(t->flags.flags); if (t->h_counters) (void)hipHostFree(t->h_counters); delete t; SR_HIP(e); }
     t->h_counters_cap = 1;
     dev->targets.push_back(t);
     *out = t;
@@ -661,7 +669,7 @@ int sr_target_destroy(sr_device dev, sr_target target)
         (void)hipSetDevice(dev->ordinal); (void)hipStreamSynchronize(dev->stream);
         dev->targets.erase(std::remove(dev->targets.begin(), dev->targets.end(), target), dev->targets.end());
     }
-    (void)hipFree(target->d_vis); (void)hipFree(target->d_color_own);
+    (void)hipFree(target->d_vis); (void)hipFree(target->d_color_own); (void)hipFree(target->flags.flags);
     if (target->h_counters) (void)hipHostFree(target->h_counters);
     delete target;
     return SR_OK;

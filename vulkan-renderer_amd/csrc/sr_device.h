@@ -73,6 +73,17 @@ struct FrameGeom {
     int samples;             // 1 or 4
 };
 
+// One flag per kFlagBlockW x kFlagBlockH pixels of every view of a target: non-zero when the block's part of the
+// visibility buffer may hold anything but the clear value.  Written by the shading pass (which sees every word),
+// read by the start of the next draw, which clears only the flagged blocks.
+constexpr uint32_t kFlagBlockW = 32, kFlagBlockH = 8;
+struct BlockFlags {
+    uint32_t* flags;   // [views of the target][nby][nbx]
+    int nbx, nby;
+    __device__ uint32_t& at(uint32_t view, uint32_t bx, uint32_t by) const { return flags[((size_t)view * nby + by) * nbx + bx]; }
+    __device__ uint32_t of(uint32_t view, int x /* pixel inside the stored rectangle */, int y) const { return at(view, (uint32_t)x / kFlagBlockW, (uint32_t)y / kFlagBlockH); }
+};
+
 // ---- vertex shader arithmetic -------------------------------------------------------------------
 __host__ __device__ inline void mat4_mul_vec4(const float* M, float x, float y, float z, float w, float* r)
 {

@@ -16,14 +16,17 @@ struct FragLaunch {
     const float* decode;
     const float* thresh;
     uint32_t view0, n_views;
+    BlockFlags flags;          // of the target
     bool identity_model;       // the model matrix of every one of these views is the identity
 };
 
 void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz);
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
                    int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out);
-// vis: n words to clear; zero16/zero_bytes: 16-byte aligned block to zero; views_*: optional 16-byte aligned copy (0 bytes = none)
-void launch_begin_pass(hipStream_t st, uint64_t* vis, size_t n, void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes);
+// vis: the target's whole visibility buffer, of which the flagged blocks of views [view0, view0 + n_views) are cleared;
+// zero16/zero_bytes: 16-byte aligned block to zero; views_*: optional 16-byte aligned copy (0 bytes = none)
+void launch_begin_pass(hipStream_t st, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0, uint32_t n_views,
+                       void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes);
 // triangle set-up (micro-triangles resolved, clip list and pending lists filled) followed by the binning of the pending lists
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0,
