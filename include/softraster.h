@@ -177,6 +177,24 @@ SR_API int sr_target_readback(sr_device dev, sr_target target, int kind, uint32_
 SR_API int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_blocks,
                    uint32_t n_views, size_t ubo_stride, const sr_texture textures[4]);
 
+/* ---- sr_draw for callers that cannot allocate.  No counterpart in the reference.  For callers that must not trigger
+ * a device allocation while they draw: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same arguments, same frame and same asynchrony as sr_draw, but every intermediate buffer of the draw (window-space
+ * vertices, binning state, pending and reference lists, clip list, per-view transforms) lives in one array of
+ * sr_no_alloc_scratch_bytes() = 64 MiB inside the library's device image -- each GPU the library runs on holds its own
+ * copy until the process ends -- and the call issues kernels only: no hipMalloc, hipFree, hipHostMalloc, event creation or
+ * copy from host memory (the transforms travel as kernel arguments).
+ * Limits: at most 8 views per call; the draw must fit the array in one pass (about 1 M triangles for one view: 48 bytes
+ * per triangle and 16 per vertex, per view), else SR_ERR_UNSUPPORTED with the sizes in sr_last_error_string(); a frame
+ * whose tile reference list does not fit what is left of the array reports the same when its target is next read.
+ * All calls on one GPU share that GPU's array, which still holds the previous call's contents (what must start at zero is
+ * zeroed by the draw itself): calls on one device handle are ordered by its stream; calls through DIFFERENT device handles
+ * of the same GPU that overlap in time race on the array and must not be made.
+ * The target, mesh and textures are created beforehand with the ordinary entry points (which do allocate). */
+SR_API int sr_draw_no_alloc(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_blocks,
+                            uint32_t n_views, size_t ubo_stride, const sr_texture textures[4]);
+SR_API size_t sr_no_alloc_scratch_bytes(void);
+
 /* ---- instrumentation (no reference counterpart) */
 SR_API int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out);
 /* When enabled, sr_draw brackets every stage with HIP events on the device's stream. */

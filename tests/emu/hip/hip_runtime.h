@@ -28,6 +28,7 @@
 #define __device__
 #define __host__
 #define __shared__ static
+#define __align__(n) __attribute__((aligned(n)))
 #define __launch_bounds__(...)
 #define __forceinline__ inline __attribute__((always_inline))
 
@@ -55,7 +56,7 @@ static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long lon
 // ---- runtime API (the subset the library calls) ----------------------------------------------------
 typedef int hipError_t;
 enum : int {
-    hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100,
+    hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidSymbol = 13, hipErrorNoDevice = 100,
     hipErrorNotReady = 600, hipErrorIllegalAddress = 700, hipErrorLaunchFailure = 719,
 };
 typedef struct hipemu_stream* hipStream_t;
@@ -72,6 +73,9 @@ struct hipDeviceProp_t {
 
 extern "C" {
 hipError_t hipGetDeviceCount(int* n);
+// a __device__ variable is an ordinary host variable here; its "device address" is its address
+#define HIP_SYMBOL(x) (&(x))
+static inline hipError_t hipGetSymbolAddress(void** ptr, const void* symbol) { *ptr = const_cast<void*>(symbol); return 0; }
 hipError_t hipSetDevice(int ordinal);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int ordinal);
 hipError_t hipGetLastError(void);

@@ -16,6 +16,17 @@
 
 using namespace sr;
 
+// Scratch of sr_draw_no_alloc (include/softraster.h): one array in the device image of this library instead of
+// allocations.  Each GPU the library runs on holds its own copy at its own address; sr_device_create looks that address up
+// once (hipGetSymbolAddress, with the device current) and from then on only the pointer is used: in host code the
+// array's name is a stand-in for the symbol, not a device address.  Every draw through that entry point on one GPU
+// shares the array and finds the previous draw's contents in it; the begin kernel zeroes what must start at zero
+// (counters, per-tile counts), everything else is written before it is read.
+constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
+constexpr uint32_t kStaticScratchViews = kMaxPackedViews;     // views of a draw whose transforms travel as kernel arguments
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -74,6 +85,7 @@ struct sr_device_t {
     std::vector<hipEvent_t> events;   // kNumStageEvents per pass of the last profiled draw
     size_t events_used = 0;
     std::vector<sr_target_t*> targets;   // live targets of this device (they may hold a reference to a mesh and textures)
+    void* static_scratch = nullptr;      // this GPU's copy of the array `scratch` (sr_api.hip), looked up at creation
 };
 
 struct sr_mesh_t {
@@ -121,6 +133,7 @@ struct sr_target_t {
     // draw is issued again in full before anything of it can be observed (finish_target), like a draw whose tile
     // reference list overflowed.
     bool lean = false;
+    bool no_alloc = false;      // the last draw came through sr_draw_no_alloc: if it is issued again, then the same way
 };
 
 namespace {
@@ -165,71 +178,106 @@ uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameG
     return (uint32_t)std::max<uint64_t>(v, 1);
 }
 
+// where the per-draw scratch of a pass lives
+struct PassScratch {
+    void* screen = nullptr; uint32_t* tile_count = nullptr; uint32_t* pending = nullptr; uint32_t* tile_offset = nullptr;
+    BinRecord* records = nullptr; uint32_t* refs = nullptr; uint64_t ref_capacity = 0; uint2* clip = nullptr; uint32_t clip_capacity = 0;
+    ViewXform* views = nullptr;
+};
+
 // issues every kernel of one draw (all passes) on the device's stream
 int issue_draw(sr_device_t* dev, sr_target_t* tg)
 {
     const sr_mesh_t* m = tg->mesh;
     const FrameGeom& g = tg->g;
     const uint32_t n_views = (uint32_t)tg->views.size();
-    const uint32_t vpp = views_per_pass(dev, m, g, n_views);
+    const bool no_alloc = tg->no_alloc;
+    const uint32_t vpp = no_alloc ? n_views : views_per_pass(dev, m, g, n_views);
     const uint32_t passes = (n_views + vpp - 1) / vpp;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
     hipStream_t st = dev->stream;
-
-    if (dev->ref_capacity == 0) dev->ref_capacity = std::max<uint64_t>((uint64_t)m->n_tris * vpp, (uint64_t)1 << 20);
-    dev->ref_capacity = std::min<uint64_t>(dev->ref_capacity, 0xFFFFFFFFull);
 
     const uint32_t bt = chunk_triangles(), sbt = setup_block_triangles();
     const uint32_t n_blocks = std::max((m->n_tris + bt - 1u) / bt, 1u);            // chunks of a view's pending list
     const uint32_t n_setup_blocks = std::max((m->n_tris + sbt - 1u) / sbt, 1u);
     const uint32_t pending_stride = n_blocks * bt;
     const size_t count_words = (size_t)vpp * n_tiles * 3;
-    SR_HIP(dev->screen.ensure((size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex)));
     // layout of the binning state: [count_small | count_large | cursor_large | pending_total per view | counters of this pass]
     // (zeroed at the start of every pass, padded to 16 bytes) [block_count: written by the binning kernel] [block_micro: by set-up]
     const size_t zero_words = (count_words + vpp + kNumPassCounters + 3) & ~(size_t)3;
-    SR_HIP(dev->tile_count.ensure((zero_words + (size_t)vpp * n_blocks + (size_t)vpp * n_setup_blocks) * 4));
-    SR_HIP(dev->pending.ensure((size_t)vpp * pending_stride * 4));
-    SR_HIP(dev->tile_offset.ensure(((size_t)vpp * n_tiles + 1) * 4));
-    SR_HIP(dev->records.ensure((size_t)vpp * n_blocks * setup_block_records() * sizeof(BinRecord)));
-    SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
-    SR_HIP(dev->clip.ensure((size_t)dev->clip_capacity * sizeof(uint2)));
     const size_t view_bytes = (size_t)n_views * sizeof(ViewXform);
-    SR_HIP(dev->views.ensure(view_bytes));
-    sr_device_t::Staging& sg = dev->staging[dev->staging_next++ & 3u];
-    if (!sg.ev) SR_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
-    if (sg.in_flight) { SR_HIP(hipEventSynchronize(sg.ev)); sg.in_flight = false; }
-    if (sg.cap < view_bytes) {
-        if (sg.h) SR_HIP(hipHostFree(sg.h));
-        sg.h = nullptr; sg.cap = 0;
-        SR_HIP(hipHostMalloc((void**)&sg.h, view_bytes, hipHostMallocMapped));
-        SR_HIP(hipHostGetDevicePointer(&sg.d, sg.h, 0));
-        sg.cap = view_bytes;
-    }
-    if (tg->h_counters_cap < passes) {
-        SR_HIP(hipStreamSynchronize(st));
-        if (tg->h_counters) SR_HIP(hipHostFree(tg->h_counters));
-        tg->h_counters = nullptr; tg->h_counters_cap = 0;
-        SR_HIP(hipHostMalloc((void**)&tg->h_counters, (size_t)passes * kCountersPerPass * 4, hipHostMallocMapped));
-        SR_HIP(hipHostGetDevicePointer(&tg->hd_counters, tg->h_counters, 0));
-        tg->h_counters_cap = passes;
-    }
-    if (dev->profiling) {
-        while (dev->events.size() < (size_t)passes * kNumStageEvents) {
-            hipEvent_t e; SR_HIP(hipEventCreate(&e));
-            dev->events.push_back(e);
+    const size_t bytes_screen = (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex);
+    const size_t bytes_tile_count = (zero_words + (size_t)vpp * n_blocks + (size_t)vpp * n_setup_blocks) * 4;
+    const size_t bytes_pending = (size_t)vpp * pending_stride * 4;
+    const size_t bytes_tile_offset = ((size_t)vpp * n_tiles + 1) * 4;
+    const size_t bytes_records = (size_t)vpp * n_blocks * setup_block_records() * sizeof(BinRecord);
+    PassScratch ps;
+    sr_device_t::Staging* staging = nullptr;
+    if (no_alloc) {
+        // carve the static array; the tile reference list takes what is left
+        size_t used = 0;
+        auto take = [&](size_t bytes) { void* p = (char*)dev->static_scratch + used; used += (bytes + 255) & ~(size_t)255; return p; };
+        ps.screen = take(bytes_screen); ps.tile_count = (uint32_t*)take(bytes_tile_count); ps.pending = (uint32_t*)take(bytes_pending);
+        ps.tile_offset = (uint32_t*)take(bytes_tile_offset); ps.records = (BinRecord*)take(bytes_records);
+        ps.views = (ViewXform*)take(view_bytes);
+        ps.clip_capacity = 1024; ps.clip = (uint2*)take((size_t)ps.clip_capacity * sizeof(uint2));
+        const size_t min_refs = (size_t)1 << 16;
+        if (used + min_refs * 4 > kStaticScratchBytes)
+            return fail(SR_ERR_UNSUPPORTED, "sr_draw_no_alloc: this draw needs " + std::to_string(used + min_refs * 4) + " bytes of scratch, the static array holds " +
+                                                std::to_string(kStaticScratchBytes) + " (fewer triangles, vertices or views, or sr_draw)");
+        ps.ref_capacity = std::min<uint64_t>((kStaticScratchBytes - used) / 4, 0xFFFFFFFFull);
+        ps.refs = (uint32_t*)((char*)dev->static_scratch + used);
+        dev->events_used = 0;
+    } else {
+        if (dev->ref_capacity == 0) dev->ref_capacity = std::max<uint64_t>((uint64_t)m->n_tris * vpp, (uint64_t)1 << 20);
+        dev->ref_capacity = std::min<uint64_t>(dev->ref_capacity, 0xFFFFFFFFull);
+        SR_HIP(dev->screen.ensure(bytes_screen));
+        SR_HIP(dev->tile_count.ensure(bytes_tile_count));
+        SR_HIP(dev->pending.ensure(bytes_pending));
+        SR_HIP(dev->tile_offset.ensure(bytes_tile_offset));
+        SR_HIP(dev->records.ensure(bytes_records));
+        SR_HIP(dev->refs.ensure((size_t)dev->ref_capacity * 4));
+        SR_HIP(dev->clip.ensure((size_t)dev->clip_capacity * sizeof(uint2)));
+        SR_HIP(dev->views.ensure(view_bytes));
+        ps.screen = dev->screen.ptr; ps.tile_count = (uint32_t*)dev->tile_count.ptr; ps.pending = (uint32_t*)dev->pending.ptr;
+        ps.tile_offset = (uint32_t*)dev->tile_offset.ptr; ps.records = (BinRecord*)dev->records.ptr; ps.refs = (uint32_t*)dev->refs.ptr;
+        ps.ref_capacity = dev->ref_capacity; ps.clip = (uint2*)dev->clip.ptr; ps.clip_capacity = dev->clip_capacity; ps.views = (ViewXform*)dev->views.ptr;
+        sr_device_t::Staging& sg = dev->staging[dev->staging_next++ & 3u];
+        staging = &sg;
+        if (!sg.ev) SR_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
+        if (sg.in_flight) { SR_HIP(hipEventSynchronize(sg.ev)); sg.in_flight = false; }
+        if (sg.cap < view_bytes) {
+            if (sg.h) SR_HIP(hipHostFree(sg.h));
+            sg.h = nullptr; sg.cap = 0;
+            SR_HIP(hipHostMalloc((void**)&sg.h, view_bytes, hipHostMallocMapped));
+            SR_HIP(hipHostGetDevicePointer(&sg.d, sg.h, 0));
+            sg.cap = view_bytes;
         }
-        dev->events_used = (size_t)passes * kNumStageEvents;
-    } else dev->events_used = 0;
-
-    std::memcpy(sg.h, tg->views.data(), view_bytes);
+        if (tg->h_counters_cap < passes) {
+            SR_HIP(hipStreamSynchronize(st));
+            if (tg->h_counters) SR_HIP(hipHostFree(tg->h_counters));
+            tg->h_counters = nullptr; tg->h_counters_cap = 0;
+            SR_HIP(hipHostMalloc((void**)&tg->h_counters, (size_t)passes * kCountersPerPass * 4, hipHostMallocMapped));
+            SR_HIP(hipHostGetDevicePointer(&tg->hd_counters, tg->h_counters, 0));
+            tg->h_counters_cap = passes;
+        }
+        if (dev->profiling) {
+            while (dev->events.size() < (size_t)passes * kNumStageEvents) {
+                hipEvent_t e; SR_HIP(hipEventCreate(&e));
+                dev->events.push_back(e);
+            }
+            dev->events_used = (size_t)passes * kNumStageEvents;
+        } else dev->events_used = 0;
+        std::memcpy(sg.h, tg->views.data(), view_bytes);
+    }
+    const bool profiling = dev->profiling && !no_alloc;
 
     ScreenPlanes sp{};
-    sp.xy = (int2*)dev->screen.ptr;
-    sp.zw = (float2*)((char*)dev->screen.ptr + (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(int2));
+    sp.xy = (int2*)ps.screen;
+    sp.zw = (float2*)((char*)ps.screen + (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(int2));
     sp.n_verts = m->n_verts;
     BinBuffers b{};
-    b.count_small = (uint32_t*)dev->tile_count.ptr;
+    b.count_small = ps.tile_count;
     b.count_large = b.count_small + (size_t)vpp * n_tiles;
     b.cursor_large = b.count_large + (size_t)vpp * n_tiles;
     b.pending_total = b.count_small + count_words;
@@ -237,14 +285,15 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     b.block_count = b.count_small + zero_words;
     b.block_micro = b.block_count + (size_t)vpp * n_blocks;
     b.n_setup_blocks = m->n_tris ? n_setup_blocks : 0u;   // (an empty mesh launches no set-up block: nothing to sum)
-    b.pending = (uint32_t*)dev->pending.ptr;
+    b.pending = ps.pending;
     b.pending_stride = pending_stride;
     b.n_blocks = n_blocks;
-    b.tile_offset = (uint32_t*)dev->tile_offset.ptr;
-    b.refs = (uint32_t*)dev->refs.ptr;
-    b.ref_capacity = (uint32_t)dev->ref_capacity;
-    b.records = (BinRecord*)dev->records.ptr;
-    ClipList clip{(uint2*)dev->clip.ptr, dev->clip_capacity};
+    b.tile_offset = ps.tile_offset;
+    b.refs = ps.refs;
+    b.ref_capacity = (uint32_t)ps.ref_capacity;
+    b.records = ps.records;
+    ClipList clip{ps.clip, ps.clip_capacity};
+    if (no_alloc) launch_store_views(st, tg->views.data(), n_views, ps.views);   // the transforms travel as kernel arguments: no staging memory
 
     const sr_texture_t* albedo = tg->tex[0];
     const sr_texture_t* metallic = tg->tex[2];
@@ -252,11 +301,12 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
 
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const uint32_t v0 = pass * vpp, nv = std::min(vpp, n_views - v0);
-        const ViewXform* d_views = (const ViewXform*)dev->views.ptr + v0;
-        hipEvent_t* ev = dev->profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
+        const ViewXform* d_views = ps.views + v0;
+        hipEvent_t* ev = profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
         if (ev) SR_HIP(hipEventRecord(ev[0], st));
-        launch_begin_pass(st, tg->d_vis, tg->flags, g, v0, nv, b.count_small, zero_words * 4, sg.d, dev->views.ptr, pass == 0 ? view_bytes : 0);
-        if (pass == 0) { SR_HIP(hipEventRecord(sg.ev, st)); sg.in_flight = true; }
+        launch_begin_pass(st, tg->d_vis, tg->flags, g, v0, nv, b.count_small, zero_words * 4, staging ? staging->d : nullptr, ps.views,
+                          pass == 0 && staging ? view_bytes : 0);
+        if (pass == 0 && staging) { SR_HIP(hipEventRecord(staging->ev, st)); staging->in_flight = true; }
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
@@ -288,7 +338,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     }
     SR_HIP(hipGetLastError());
     tg->passes = passes;
-    tg->capacity_at_draw = dev->ref_capacity;
+    tg->capacity_at_draw = ps.ref_capacity;
     tg->check_pending = true;
     return SR_OK;
 }
@@ -310,6 +360,8 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
         if (!lean_missed && worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
         if (attempt == 2) break;
         if (lean_missed) tg->lean = false;
+        else if (tg->no_alloc) return fail(SR_ERR_UNSUPPORTED, "sr_draw_no_alloc: the frame needs " + std::to_string(worst) + " tile references, the static scratch holds " +
+                                                                    std::to_string(tg->capacity_at_draw) + " after this draw's other buffers (use sr_draw)");
         else dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull);
         int rc = issue_draw(dev, tg);
         if (rc != SR_OK) return rc;
@@ -386,6 +438,9 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (e == hipSuccess) e = hipMalloc((void**)&dev->d_thresh, sizeof thr);
     if (e == hipSuccess) e = hipMemcpy(dev->d_decode, dec, sizeof dec, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dev->d_thresh, thr, sizeof thr, hipMemcpyHostToDevice);
+    // this GPU's copy of the static scratch array (the device is current: hipSetDevice above)
+    if (e == hipSuccess) e = hipGetSymbolAddress(&dev->static_scratch, HIP_SYMBOL(scratch));
+    if (e == hipSuccess && dev->static_scratch == nullptr) e = hipErrorInvalidSymbol;
     if (e != hipSuccess) { (void)sr_device_destroy(dev); SR_HIP(e); }
     if (const char* v = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(v);
     if (const char* v = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 30;
@@ -657,6 +712,7 @@ int sr_target_create(sr_device dev, int width, int height, int samples, uint32_t
     if (e == hipSuccess) e = hipHostGetDevicePointer(&t->hd_counters, t->h_counters, 0);
     if (e != hipSuccess) { (void)hipFree(t->d_vis); (void)hipFree(t->d_color_own); (void)hipFree(t->flags.flags); if (t->h_counters) (void)hipHostFree(t->h_counters); delete t; SR_HIP(e); }
     t->h_counters_cap = 1;
+    t->views.reserve(n_views);      // a later draw does not allocate host memory for them either
     dev->targets.push_back(t);
     *out = t;
     return SR_OK;
@@ -721,15 +777,18 @@ int sr_target_readback(sr_device dev, sr_target target, int kind, uint32_t view,
 }
 
 // ---- draw ---------------------------------------------------------------------------------------
-int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_blocks, uint32_t n_views, size_t ubo_stride, const sr_texture textures[4])
+static int draw_common(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_blocks, uint32_t n_views, size_t ubo_stride, const sr_texture textures[4],
+                       bool no_alloc)
 {
     if (!dev || !target || !mesh || !ubo_blocks || !textures) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (no_alloc && n_views > kStaticScratchViews)
+        return fail(SR_ERR_UNSUPPORTED, "sr_draw_no_alloc draws at most " + std::to_string(kStaticScratchViews) + " views per call");
     if (n_views == 0 || n_views > target->n_views) return fail(SR_ERR_INVALID_ARGUMENT, "n_views must be in 1..target views");
     if (ubo_stride < 204 || (ubo_stride & 3)) return fail(SR_ERR_INVALID_ARGUMENT, "ubo_stride must be >= 204 and a multiple of 4");
     if (!textures[0] || !textures[2] || !textures[3]) return fail(SR_ERR_INVALID_ARGUMENT, "albedo, metallic and roughness textures are required");
     SR_HIP(hipSetDevice(dev->ordinal));
     // a finished earlier draw tells how many tile references the scene needs: grow before reuse
-    if (target->check_pending && hipStreamQuery(dev->stream) == hipSuccess) {
+    if (!no_alloc && target->check_pending && hipStreamQuery(dev->stream) == hipSuccess) {
         for (uint32_t p = 0; p < target->passes; ++p)
             if (target->h_counters[(size_t)p * kCountersPerPass] > dev->ref_capacity) {
                 const uint64_t w = target->h_counters[(size_t)p * kCountersPerPass];
@@ -760,8 +819,21 @@ int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_block
         x.model_is_identity = std::memcmp(x.model, identity, 64) == 0 ? 1.0f : 0.0f;
     }
     target->drawn = true;
+    target->no_alloc = no_alloc;
     return issue_draw(dev, target);
 }
+
+int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_blocks, uint32_t n_views, size_t ubo_stride, const sr_texture textures[4])
+{
+    return draw_common(dev, target, mesh, ubo_blocks, n_views, ubo_stride, textures, false);
+}
+
+int sr_draw_no_alloc(sr_device dev, sr_target target, sr_mesh mesh, const void* ubo_blocks, uint32_t n_views, size_t ubo_stride, const sr_texture textures[4])
+{
+    return draw_common(dev, target, mesh, ubo_blocks, n_views, ubo_stride, textures, true);
+}
+
+size_t sr_no_alloc_scratch_bytes(void) { return kStaticScratchBytes; }
 
 // ---- instrumentation ----------------------------------------------------------------------------
 int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)

@@ -49,6 +49,15 @@ __global__ __launch_bounds__(256) void begin_pass_kernel(unsigned long long* __r
     for (int i = 0; i < n; ++i) cell[i] = kVisClear;
 }
 
+// The per-view transforms of a draw that may not touch staging memory: they arrive as kernel arguments.
+struct ViewPack { ViewXform v[kMaxPackedViews]; };
+__global__ __launch_bounds__(64) void store_views_kernel(ViewPack pack, uint32_t n, ViewXform* __restrict__ dst)
+{
+    constexpr uint32_t kWords = sizeof(ViewXform) / 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&pack);
+    for (uint32_t i = threadIdx.x; i < n * kWords; i += 64u) reinterpret_cast<uint32_t*>(dst)[i] = src[i];
+}
+
 // =================================================================================================
 // stage 1: vertex shader (shaders/shader.vert:20-27) + perspective divide + viewport + snapping
 // one thread per (vertex, view); coalesced 4-byte plane loads, one 16-byte store
@@ -1389,6 +1398,14 @@ void launch_begin_pass(hipStream_t st, uint64_t* vis, const BlockFlags& flags, c
     const dim3 grid(div_up((uint32_t)g.rw, 64), div_up((uint32_t)g.rh, 8), std::max(n_views, 1u));
     begin_pass_kernel<<<grid, 256, 0, st>>>((unsigned long long*)vis, flags, g.rw, g.rh, g.samples, view0,
                                             (uint4*)zero16, zero_bytes / 16, (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
+}
+
+void launch_store_views(hipStream_t st, const ViewXform* host_views, uint32_t n, ViewXform* dst)
+{
+    ViewPack pack;
+    n = std::min(n, kMaxPackedViews);
+    std::memcpy(pack.v, host_views, (size_t)n * sizeof(ViewXform));
+    if (n) store_views_kernel<<<1, 64, 0, st>>>(pack, n, dst);
 }
 
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,

@@ -20,6 +20,9 @@ struct FragLaunch {
     bool identity_model;       // the model matrix of every one of these views is the identity
 };
 
+constexpr uint32_t kMaxPackedViews = 8;   // views whose transforms fit the kernel arguments of launch_store_views
+// writes n (<= kMaxPackedViews) per-view transforms from host memory to dst without any copy or staging buffer
+void launch_store_views(hipStream_t st, const ViewXform* host_views, uint32_t n, ViewXform* dst);
 void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz);
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
                    int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out);

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "sr_target_readback", "sr_draw", "sr_draw_get_stats", "sr_profile_enable", "sr_profile_get", "sr_debug_vertex_stage",
     "sr_texture_size", "sr_texture_create_from_file", "sr_image_read_file", "sr_image_free",
     "sr_model_load", "sr_model_mesh_count", "sr_model_mesh", "sr_model_destroy", "sr_model_read_file", "sr_model_mesh_data",
+    "sr_draw_no_alloc", "sr_no_alloc_scratch_bytes",
 )
 
 
@@ -115,6 +116,8 @@ def load_library():
     L.sr_target_bind_color.argtypes = [vp, vp, vp]
     L.sr_target_readback.argtypes = [vp, vp, C.c_int, u32, vp, sz]
     L.sr_draw.argtypes = [vp, vp, vp, vp, u32, sz, C.POINTER(vp)]
+    L.sr_draw_no_alloc.argtypes = [vp, vp, vp, vp, u32, sz, C.POINTER(vp)]
+    L.sr_no_alloc_scratch_bytes.restype = sz
     L.sr_draw_get_stats.argtypes = [vp, vp, C.POINTER(DrawStats)]
     L.sr_profile_enable.argtypes = [vp, C.c_int]
     L.sr_profile_get.argtypes = [vp, C.POINTER(StageTimes)]
@@ -365,9 +368,10 @@ class RenderTarget:
         return s.as_dict()
 
 
-def draw(device: Device, target: RenderTarget, mesh: StaticMesh, ubo_blocks: np.ndarray, textures):
+def draw(device: Device, target: RenderTarget, mesh: StaticMesh, ubo_blocks: np.ndarray, textures, no_alloc: bool = False):
     """ubo_blocks: (n_views, 52) float32 uniform blocks (or (52,) for one view); textures: 4 Texture
-    objects in binding order albedo, normal, metallic, roughness (normal may be None).  Asynchronous."""
+    objects in binding order albedo, normal, metallic, roughness (normal may be None).  Asynchronous.
+    no_alloc: through sr_draw_no_alloc (every intermediate buffer in the library's static device array; at most 8 views)."""
     u = np.ascontiguousarray(ubo_blocks, np.float32)
     if u.ndim == 1:
         u = u.reshape(1, -1)
@@ -376,4 +380,5 @@ def draw(device: Device, target: RenderTarget, mesh: StaticMesh, ubo_blocks: np.
     if u.shape[1] != 52:
         u = np.ascontiguousarray(np.concatenate([u[:, :51], np.zeros((u.shape[0], 1), np.float32)], axis=1))
     arr = (C.c_void_p * 4)(*[t._h if t is not None else None for t in textures])
-    _check(device._lib.sr_draw(device._h, target._h, mesh._h, u.ctypes.data, u.shape[0], u.shape[1] * 4, arr), "sr_draw")
+    entry = device._lib.sr_draw_no_alloc if no_alloc else device._lib.sr_draw
+    _check(entry(device._h, target._h, mesh._h, u.ctypes.data, u.shape[0], u.shape[1] * 4, arr), "sr_draw_no_alloc" if no_alloc else "sr_draw")
