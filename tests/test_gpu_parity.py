@@ -207,11 +207,7 @@ def test_mesh_and_textures_destroyed_before_the_read_back(sr, oracle):
     W, H = 320, 200
     ubo = sr.scene.default_camera_ubo(W, H)
     images = sr.scene.material_textures(32)
-    os.environ["SR_REF_CAPACITY"] = "64"     # far too small: the first draw overflows and must be repeated
-    try:
-        dev = sr.Device(0)
-    finally:
-        del os.environ["SR_REF_CAPACITY"]
+    dev = util.device_with_env(sr, SR_REF_CAPACITY="64")
     try:
         mesh = sr.create_mesh_from_data(dev, verts, idx)
         tex = [sr.create_texture(dev, im) for im in images]
@@ -346,11 +342,7 @@ def test_tile_reference_list_grows_and_the_draw_is_repeated(sr, oracle, samples)
     W, H = 320, 200
     ubos = sr.scene.orbit_ubos(2, W, H)
     images = sr.scene.material_textures(32)
-    os.environ["SR_REF_CAPACITY"] = "64"
-    try:
-        dev = sr.Device(0)
-    finally:
-        del os.environ["SR_REF_CAPACITY"]
+    dev = util.device_with_env(sr, SR_REF_CAPACITY="64")
     try:
         for attempt in range(2):   # the second frame finds the list already large enough
             got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples)
@@ -409,11 +401,7 @@ def test_near_plane_clipper(sr, oracle, samples):
         assert (got[0]["tri"] != sr.NO_TRIANGLE).mean() > 0.9 and (got[2]["tri"] < 2).sum() > W * H // 4
     finally:
         dev.close()
-    os.environ["SR_CLIP_CAPACITY"] = "8"
-    try:
-        dev = sr.Device(0)
-    finally:
-        del os.environ["SR_CLIP_CAPACITY"]
+    dev = util.device_with_env(sr, SR_CLIP_CAPACITY="8")
     try:
         st = util.gpu_render(sr, dev, verts, idx, images, ubos[:1], W, H, samples)[0]["stats"]
         ref = oracle.draw(ubos[0], verts, idx, images, W, H, samples, shade=False)["stats"]
@@ -445,11 +433,7 @@ def test_more_distinct_tiles_than_a_binning_block_can_hash(sr, oracle):
     eye = np.eye(4, dtype=np.float32)
     ubo = sr.scene.make_ubo(eye, eye, eye, (0.0, 0.0, 5.0))
     images = sr.scene.material_textures(16)
-    os.environ["SR_TILE_LOG2"] = "4"
-    try:
-        dev = sr.Device(0)
-    finally:
-        del os.environ["SR_TILE_LOG2"]
+    dev = util.device_with_env(sr, SR_TILE_LOG2="4")
     try:
         got = util.gpu_render(sr, dev, verts, idx, images, ubo, W, H, 4)[0]
         st = got["stats"]
@@ -469,11 +453,7 @@ def test_view_batch_split_into_passes(sr, oracle, device, samples):
     n_views, W, H = 13, 200, 120
     ubos = sr.scene.orbit_ubos(n_views, W, H)
     images = sr.scene.material_textures(32)
-    os.environ["SR_SCRATCH_MIB"] = "1"
-    try:
-        dev = sr.Device(0)
-    finally:
-        del os.environ["SR_SCRATCH_MIB"]
+    dev = util.device_with_env(sr, SR_SCRATCH_MIB="1")
     try:
         got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples)
         for k in range(n_views):

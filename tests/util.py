@@ -55,3 +55,19 @@ def assert_visibility_equal(got, ref):
     assert np.array_equal(got["tri"], ref["tri"]), f"triangle ids differ at {int((got['tri'] != ref['tri']).sum())} samples"
     assert np.array_equal(got["depth"].view(np.uint32), ref["depth"].view(np.uint32)), \
         f"depth bits differ at {int((got['depth'].view(np.uint32) != ref['depth'].view(np.uint32)).sum())} samples"
+
+
+def device_with_env(sr, **env):
+    """A device handle created while the given environment variables are set (sr_device_create reads its settings
+    from the environment); the environment is put back as it was."""
+    import os
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return sr.Device(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

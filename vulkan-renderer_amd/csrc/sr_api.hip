@@ -197,17 +197,16 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
     hipStream_t st = dev->stream;
 
-    const uint32_t bt = chunk_triangles(), sbt = setup_block_triangles();
+    const uint32_t bt = chunk_triangles();
     const uint32_t n_blocks = std::max((m->n_tris + bt - 1u) / bt, 1u);            // chunks of a view's pending list
-    const uint32_t n_setup_blocks = std::max((m->n_tris + sbt - 1u) / sbt, 1u);
     const uint32_t pending_stride = n_blocks * bt;
     const size_t count_words = (size_t)vpp * n_tiles * 3;
-    // layout of the binning state: [count_small | count_large | cursor_large | pending_total per view | counters of this pass]
-    // (zeroed at the start of every pass, padded to 16 bytes) [block_count: written by the binning kernel] [block_micro: by set-up]
-    const size_t zero_words = (count_words + vpp + kNumPassCounters + 3) & ~(size_t)3;
+    // layout of the binning state: [count_small | count_large | cursor_large | pending_total per view | counters of this pass |
+    // spread micro-triangle counters] (zeroed at the start of every pass, padded to 16 bytes) [block_count: written by the binning kernel]
+    const size_t zero_words = (count_words + vpp + kNumPassCounters + kMicroSpread * kMicroSpreadStride + 3) & ~(size_t)3;
     const size_t view_bytes = (size_t)n_views * sizeof(ViewXform);
     const size_t bytes_screen = (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex);
-    const size_t bytes_tile_count = (zero_words + (size_t)vpp * n_blocks + (size_t)vpp * n_setup_blocks) * 4;
+    const size_t bytes_tile_count = (zero_words + (size_t)vpp * n_blocks) * 4;
     const size_t bytes_pending = (size_t)vpp * pending_stride * 4;
     const size_t bytes_tile_offset = ((size_t)vpp * n_tiles + 1) * 4;
     const size_t bytes_records = (size_t)vpp * n_blocks * setup_block_records() * sizeof(BinRecord);
@@ -242,16 +241,19 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         ps.screen = dev->screen.ptr; ps.tile_count = (uint32_t*)dev->tile_count.ptr; ps.pending = (uint32_t*)dev->pending.ptr;
         ps.tile_offset = (uint32_t*)dev->tile_offset.ptr; ps.records = (BinRecord*)dev->records.ptr; ps.refs = (uint32_t*)dev->refs.ptr;
         ps.ref_capacity = dev->ref_capacity; ps.clip = (uint2*)dev->clip.ptr; ps.clip_capacity = dev->clip_capacity; ps.views = (ViewXform*)dev->views.ptr;
-        sr_device_t::Staging& sg = dev->staging[dev->staging_next++ & 3u];
-        staging = &sg;
-        if (!sg.ev) SR_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
-        if (sg.in_flight) { SR_HIP(hipEventSynchronize(sg.ev)); sg.in_flight = false; }
-        if (sg.cap < view_bytes) {
-            if (sg.h) SR_HIP(hipHostFree(sg.h));
-            sg.h = nullptr; sg.cap = 0;
-            SR_HIP(hipHostMalloc((void**)&sg.h, view_bytes, hipHostMallocMapped));
-            SR_HIP(hipHostGetDevicePointer(&sg.d, sg.h, 0));
-            sg.cap = view_bytes;
+        if (n_views > kMaxPackedViews) {    // too many transforms for kernel arguments: through pinned staging memory
+            sr_device_t::Staging& sg = dev->staging[dev->staging_next++ & 3u];
+            staging = &sg;
+            if (!sg.ev) SR_HIP(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
+            if (sg.in_flight) { SR_HIP(hipEventSynchronize(sg.ev)); sg.in_flight = false; }
+            if (sg.cap < view_bytes) {
+                if (sg.h) SR_HIP(hipHostFree(sg.h));
+                sg.h = nullptr; sg.cap = 0;
+                SR_HIP(hipHostMalloc((void**)&sg.h, view_bytes, hipHostMallocMapped));
+                SR_HIP(hipHostGetDevicePointer(&sg.d, sg.h, 0));
+                sg.cap = view_bytes;
+            }
+            std::memcpy(sg.h, tg->views.data(), view_bytes);
         }
         if (tg->h_counters_cap < passes) {
             SR_HIP(hipStreamSynchronize(st));
@@ -268,13 +270,12 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
             }
             dev->events_used = (size_t)passes * kNumStageEvents;
         } else dev->events_used = 0;
-        std::memcpy(sg.h, tg->views.data(), view_bytes);
     }
     const bool profiling = dev->profiling && !no_alloc;
 
     ScreenPlanes sp{};
     sp.xy = (int2*)ps.screen;
-    sp.zw = (float2*)((char*)ps.screen + (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(int2));
+    sp.z = (float*)((char*)ps.screen + (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(int2));
     sp.n_verts = m->n_verts;
     BinBuffers b{};
     b.count_small = ps.tile_count;
@@ -283,8 +284,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     b.pending_total = b.count_small + count_words;
     b.counters = b.pending_total + vpp;
     b.block_count = b.count_small + zero_words;
-    b.block_micro = b.block_count + (size_t)vpp * n_blocks;
-    b.n_setup_blocks = m->n_tris ? n_setup_blocks : 0u;   // (an empty mesh launches no set-up block: nothing to sum)
+    b.micro_spread = b.counters + kNumPassCounters;
     b.pending = ps.pending;
     b.pending_stride = pending_stride;
     b.n_blocks = n_blocks;
@@ -293,7 +293,10 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     b.ref_capacity = (uint32_t)ps.ref_capacity;
     b.records = ps.records;
     ClipList clip{ps.clip, ps.clip_capacity};
-    if (no_alloc) launch_store_views(st, tg->views.data(), n_views, ps.views);   // the transforms travel as kernel arguments: no staging memory
+    // the transforms of a draw of a few views travel as kernel arguments (of the kernel that starts the pass, or, for a mesh
+    // without vertices, of a kernel of their own): no staging memory
+    const bool views_by_argument = n_views <= kMaxPackedViews;
+    if (views_by_argument && m->n_verts == 0) launch_store_views(st, tg->views.data(), n_views, ps.views);
 
     const sr_texture_t* albedo = tg->tex[0];
     const sr_texture_t* metallic = tg->tex[2];
@@ -304,18 +307,24 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         const ViewXform* d_views = ps.views + v0;
         hipEvent_t* ev = profiling ? &dev->events[(size_t)pass * kNumStageEvents] : nullptr;
         if (ev) SR_HIP(hipEventRecord(ev[0], st));
-        launch_begin_pass(st, tg->d_vis, tg->flags, g, v0, nv, b.count_small, zero_words * 4, staging ? staging->d : nullptr, ps.views,
-                          pass == 0 && staging ? view_bytes : 0);
-        if (pass == 0 && staging) { SR_HIP(hipEventRecord(staging->ev, st)); staging->in_flight = true; }
+        // one launch starts the pass and runs the vertex stage when the transforms fit its arguments (then n_views == nv: one pass)
+        const bool fused = views_by_argument &&
+                           launch_vertex_and_begin(st, m->px, m->py, m->pz, m->n_verts, tg->views.data() + v0, nv, ps.views + v0, g.W, g.H, sp, tg->d_vis, tg->flags, g, v0,
+                                                   b.count_small, zero_words * 4);
+        if (!fused) {
+            const bool copy_views = pass == 0 && staging && !views_by_argument;
+            launch_begin_pass(st, tg->d_vis, tg->flags, g, v0, nv, b.count_small, zero_words * 4, copy_views ? staging->d : nullptr, ps.views,
+                              copy_views ? view_bytes : 0);
+            if (copy_views) { SR_HIP(hipEventRecord(staging->ev, st)); staging->in_flight = true; }
+        }
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
-        launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
+        if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
         launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, !tg->lean);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
-        if (tg->lean) {
-            launch_scan(st, b, 0, nv, pass_counters);   // nothing to scan: reports the counters of the pass
+        if (tg->lean) {   // the shading pass reports the counters of the pass
             if (ev) { SR_HIP(hipEventRecord(ev[5], st)); SR_HIP(hipEventRecord(ev[6], st)); }
         } else {
             // (before the scan kernel, which reports the counters to the host)
@@ -331,6 +340,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         f.idx = m->d_idx; f.verts_aos = m->d_aos; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv; f.flags = tg->flags;
+        f.report = PassReport{b.counters, b.pending_total, nv, b.micro_spread, tg->lean ? pass_counters : nullptr};
         f.identity_model = true;
         for (uint32_t v = v0; v < v0 + nv; ++v) f.identity_model = f.identity_model && tg->views[v].model_is_identity != 0.0f;
         launch_fragment(st, f);
@@ -923,7 +933,7 @@ int sr_debug_vertex_stage(sr_device dev, sr_mesh mesh, const void* ubo_block, in
     if (e == hipSuccess) e = hipMemcpy(d_view, &x, sizeof x, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         ScreenPlanes sp{};
-        sp.xy = (int2*)d_planes; sp.zw = (float2*)((char*)d_planes + (size_t)n * 8); sp.n_verts = n;
+        sp.xy = (int2*)d_planes; sp.z = (float*)((char*)d_planes + (size_t)n * 8); sp.n_verts = n;
         launch_vertex(dev->stream, mesh->px, mesh->py, mesh->pz, n, (const ViewXform*)d_view, 1, width, height, sp, (ScreenVertex*)d_screen, (float*)d_clip);
         e = hipStreamSynchronize(dev->stream);
     }

@@ -41,21 +41,15 @@ struct ScreenVertex {    // 16 bytes; rw == 0 marks a vertex that cannot be proj
     float rw;            // 1 / w_clip
 };
 
-// Window-space vertices of a pass are stored as two planes, so that a stage only pulls the half it
-// needs through the caches: triangle set-up reads xy only, the rasteriser xy and z.
+// Window-space vertices of a pass are stored as two planes, so that a stage only pulls what it
+// needs through the caches: triangle set-up reads xy only, and z only for the triangles that cover a sample.
+// (1/w is not stored: the shading pass recomputes the vertices it needs from the positions.)
 constexpr int32_t kBadVertexX = INT32_MIN;   // xy.x of a vertex that cannot be projected
 struct ScreenPlanes {
     int2* xy;      // [views][n_verts]: window x, y in 1/256 pixel
-    float2* zw;    // [views][n_verts]: depth, 1/w (0 for an unprojectable vertex)
+    float* z;      // [views][n_verts]: depth
     uint32_t n_verts;
 };
-__device__ inline ScreenVertex load_screen_vertex(const ScreenPlanes& sp, size_t i)
-{
-    const int2 a = sp.xy[i];
-    const float2 b = sp.zw[i];
-    ScreenVertex v; v.X = a.x; v.Y = a.y; v.z = b.x; v.rw = b.y;
-    return v;
-}
 
 struct TexDesc {
     const uint32_t* texels;  // RGBA8, all levels back to back
@@ -221,6 +215,7 @@ enum : uint32_t {
     kCtrClipped = 8,       // triangles the near-plane clipper cut and drew
     kNumPassCounters = 16,
 };
+constexpr uint32_t kMicroSpread = 64, kMicroSpreadStride = 64;   // counters, words between them (256 bytes)
 
 struct BinBuffers {
     // per (view, tile) counters, zeroed at the start of a pass: [3][views*tiles]
@@ -238,9 +233,21 @@ struct BinBuffers {
                               // each chunk owns one segment
     uint32_t* block_count;    // [views][chunks]: records written for each chunk
     uint32_t n_blocks;        // chunks per view at most
-    uint32_t* block_micro;    // [views][n_setup_blocks]: micro-triangles each set-up block resolved itself (instrumentation)
-    uint32_t n_setup_blocks;  // set-up blocks per view
+    uint32_t* micro_spread;   // [kMicroSpread * kMicroSpreadStride], zeroed at the start of a pass: micro-triangles the set-up blocks resolved
+                              // themselves (instrumentation).  Block b adds to counter b % kMicroSpread; the counters sit a cache line
+                              // apart, so that ten thousand blocks do not queue up on one address of the memory-side atomic units.
     uint32_t* counters;       // [kNumPassCounters]
+};
+
+// What the kernel that closes the geometry part of a pass tells the host (pinned memory, 8 words: tile references, -,
+// unprojectable, binned, micro, clip-listed, clipped, -): the scan kernel does, or, in a draw issued without it, the first
+// workgroup of the shading pass.
+struct PassReport {
+    const uint32_t* counters;        // [kNumPassCounters]
+    const uint32_t* pending_total;   // [n_views]
+    uint32_t n_views;
+    const uint32_t* micro_spread;    // [kMicroSpread * kMicroSpreadStride]
+    uint32_t* host_counters;         // null: nothing to report
 };
 
 // Near-plane clipping.  A triangle with one or two vertices that cannot be projected (w <= 0, or outside the guard

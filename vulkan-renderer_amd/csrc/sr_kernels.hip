@@ -30,23 +30,39 @@ __global__ __launch_bounds__(256) void split_positions_kernel(const float4* __re
 // of the block is covered; a block whose flag is clear holds nothing but the clear value.  In the 10 M-triangle 4K frame
 // 77 % of the frame is background: 15 MB of stores instead of 66.  One work-item per two pixels of a row.
 // =================================================================================================
-__global__ __launch_bounds__(256) void begin_pass_kernel(unsigned long long* __restrict__ vis, BlockFlags flags, int rw, int rh, int S, uint32_t view0,
-                                                         uint4* __restrict__ zero4, size_t n_zero4,
-                                                         const uint4* __restrict__ views_src, uint4* __restrict__ views_dst, uint32_t n_views4)
+struct BeginWork {
+    unsigned long long* vis;     // the target's whole visibility buffer
+    BlockFlags flags;
+    int rw, rh, S;
+    uint32_t view0, n_views;     // views of the pass
+    uint4* zero4; size_t n_zero4;   // binning counters to zero
+};
+// clears the two pixels of clear item `item` of the pass (items: views x rows x pixel pairs of a row) if their block is flagged
+__device__ inline void clear_item(const BeginWork& w, size_t item)
 {
-    const size_t block_id = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const size_t gtid = block_id * 256u + threadIdx.x, gstride = (size_t)gridDim.x * gridDim.y * gridDim.z * 256u;
-    if (block_id == 0)
-        for (uint32_t i = threadIdx.x; i < n_views4; i += 256u) views_dst[i] = views_src[i];
-    for (size_t i = gtid; i < n_zero4; i += gstride) zero4[i] = make_uint4(0u, 0u, 0u, 0u);
-    // the workgroup covers 64 x 8 pixels = two flag blocks side by side
-    const int x = (int)(blockIdx.x * 64u + 2u * (threadIdx.x & 31u)), y = (int)(blockIdx.y * 8u + (threadIdx.x >> 5));
-    const uint32_t view = view0 + blockIdx.z;
-    if (x >= rw || y >= rh) return;
-    if (flags.of(view, x, y) == 0u) return;
-    unsigned long long* cell = vis + (((size_t)view * rh + y) * rw + x) * S;
-    const int n = (x + 1 < rw ? 2 : 1) * S;
+    const uint32_t pairs = (uint32_t)(w.rw + 1) >> 1;
+    const size_t per_view = (size_t)pairs * (uint32_t)w.rh;
+    const uint32_t view = w.view0 + (uint32_t)(item / per_view);
+    const uint32_t rem = (uint32_t)(item % per_view);
+    const int y = (int)(rem / pairs), x = (int)(rem % pairs) * 2;
+    if (w.flags.of(view, x, y) == 0u) return;
+    unsigned long long* cell = w.vis + (((size_t)view * w.rh + y) * w.rw + x) * w.S;
+    const int n = (x + 1 < w.rw ? 2 : 1) * w.S;
     for (int i = 0; i < n; ++i) cell[i] = kVisClear;
+}
+__device__ inline void begin_work(const BeginWork& w, size_t gtid, size_t gstride)
+{
+    for (size_t i = gtid; i < w.n_zero4; i += gstride) w.zero4[i] = make_uint4(0u, 0u, 0u, 0u);
+    const size_t items = (size_t)(((uint32_t)w.rw + 1u) >> 1) * (uint32_t)w.rh * w.n_views;
+    for (size_t i = gtid; i < items; i += gstride) clear_item(w, i);
+}
+
+__global__ __launch_bounds__(256) void begin_pass_kernel(BeginWork w, const uint4* __restrict__ views_src, uint4* __restrict__ views_dst, uint32_t n_views4)
+{
+    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x, gstride = (size_t)gridDim.x * 256u;
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < n_views4; i += 256u) views_dst[i] = views_src[i];
+    begin_work(w, gtid, gstride);
 }
 
 // The per-view transforms of a draw that may not touch staging memory: they arrive as kernel arguments.
@@ -62,6 +78,32 @@ __global__ __launch_bounds__(64) void store_views_kernel(ViewPack pack, uint32_t
 // stage 1: vertex shader (shaders/shader.vert:20-27) + perspective divide + viewport + snapping
 // one thread per (vertex, view); coalesced 4-byte plane loads, one 16-byte store
 // =================================================================================================
+// The start of a pass folded into the vertex kernel (a draw of a few views, whose transforms fit the kernel arguments):
+// the same launch clears the flagged blocks of the visibility buffer, zeroes the binning counters and leaves the
+// transforms in device memory for the later kernels -- its stores ride along with the vertex stage's loads, and the pass
+// is one launch shorter.  Everything it writes is first read by the kernels that follow.
+__global__ __launch_bounds__(256) void vertex_begin_kernel(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                           uint32_t n, ViewPack pack, ViewXform* __restrict__ views_dst, int W, int H,
+                                                           ScreenPlanes out, BeginWork w)
+{
+    const size_t block_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t gtid = block_id * 256u + threadIdx.x, gstride = (size_t)gridDim.x * gridDim.y * 256u;
+    if (block_id == 0) {
+        constexpr uint32_t kWords = sizeof(ViewXform) / 4;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&pack);
+        for (uint32_t i = threadIdx.x; i < w.n_views * kWords; i += 256u) reinterpret_cast<uint32_t*>(views_dst)[i] = src[i];
+    }
+    begin_work(w, gtid, gstride);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t view = blockIdx.y;
+    if (i >= n) return;
+    float clip[4];
+    const ScreenVertex sv = project_vertex(pack.v[view], px[i], py[i], pz[i], W, H, clip);
+    const size_t o = (size_t)view * n + i;
+    out.xy[o] = make_int2(sv.rw == 0.0f ? kBadVertexX : sv.X, sv.Y);
+    out.z[o] = sv.z;
+}
+
 __global__ __launch_bounds__(256) void vertex_kernel(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                      uint32_t n, const ViewXform* __restrict__ views, int W, int H,
                                                      ScreenPlanes out, ScreenVertex* __restrict__ debug_out, float4* __restrict__ clip_out)
@@ -74,7 +116,7 @@ __global__ __launch_bounds__(256) void vertex_kernel(const float* __restrict__ p
     const ScreenVertex sv = project_vertex(vx, px[i], py[i], pz[i], W, H, clip);
     const size_t o = (size_t)view * n + i;
     out.xy[o] = make_int2(sv.rw == 0.0f ? kBadVertexX : sv.X, sv.Y);
-    out.zw[o] = make_float2(sv.z, sv.rw);
+    out.z[o] = sv.z;
     if (debug_out) debug_out[o] = sv;
     if (clip_out) clip_out[o] = make_float4(clip[0], clip[1], clip[2], clip[3]);
 }
@@ -276,13 +318,13 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     }
     // micro-triangles with a covered sample: fetch the three depths (all loads first), then resolve
     {
-        const float2* zw = sp.zw + (size_t)view * sp.n_verts;
+        const float* zp = sp.z + (size_t)view * sp.n_verts;
         unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
         float z0[kSetupTris], z1[kSetupTris], z2[kSetupTris];
 #pragma unroll
         for (uint32_t k = 0; k < kSetupTris; ++k) {
             z0[k] = z1[k] = z2[k] = 0.0f;
-            if (micro_cov[k]) { z0[k] = zw[i0[k]].x; z1[k] = zw[i1[k]].x; z2[k] = zw[i2[k]].x; }
+            if (micro_cov[k]) { z0[k] = zp[i0[k]]; z1[k] = zp[i1[k]]; z2[k] = zp[i2[k]]; }
         }
 #pragma unroll
         for (uint32_t k = 0; k < kSetupTris; ++k) {
@@ -311,8 +353,9 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
 #pragma unroll
     for (uint32_t k = 0; k < kSetupTris * 4u; ++k) total += s_wave[k];
     if (tid == 0) {
-        // (a counter of its own per block, summed by the scan kernel: ten thousand atomic adds on one address cost the kernel 15 % of its time)
-        b.block_micro[(size_t)view * gridDim.x + blk] = s_micro[0] + s_micro[1] + s_micro[2] + s_micro[3];
+        // (spread over kMicroSpread counters a cache line apart: ten thousand atomic adds on ONE address cost the kernel 15 % of its time)
+        const uint32_t micro = s_micro[0] + s_micro[1] + s_micro[2] + s_micro[3];
+        if (micro) atomicAdd(&b.micro_spread[(blk % kMicroSpread) * kMicroSpreadStride], micro);
         s_base = total ? atomicAdd(&b.pending_total[view], total) : 0u;
     }
     if (total == 0) return;   // uniform over the block
@@ -513,7 +556,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
 __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ count_a, const uint32_t* __restrict__ count_b, uint32_t n,
                                                     uint32_t* __restrict__ offset, uint32_t* __restrict__ counters,
                                                     const uint32_t* __restrict__ pending_total, uint32_t n_views,
-                                                    const uint32_t* __restrict__ block_micro, uint32_t n_block_micro,
+                                                    const uint32_t* __restrict__ micro_spread,
                                                     uint32_t* __restrict__ host_counters)
 {
     __shared__ uint32_t part[1024];
@@ -536,8 +579,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
     for (uint32_t i = beg; i < end; ++i) { offset[i] = run; run += count_a[i] + count_b[i]; }
     if (tid == 1023u) { offset[n] = part[1023]; counters[kCtrRefs] = part[1023]; }
     // micro-triangles resolved by the set-up blocks (instrumentation)
-    uint32_t micro = 0;
-    for (uint32_t i = tid; i < n_block_micro; i += 1024u) micro += block_micro[i];
+    uint32_t micro = tid < kMicroSpread ? micro_spread[tid * kMicroSpreadStride] : 0u;
     for (int o = 32; o > 0; o >>= 1) micro += (uint32_t)__shfl_down((int)micro, o);
     if ((tid & 63u) == 0u && micro) atomicAdd(&s_micro_total, micro);
     __syncthreads();
@@ -659,7 +701,7 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
     for (int i = tid; i < T * T * S; i += TPB) tile[i] = kVisClear;
     __syncthreads();
     const int2* xy = sp.xy + (size_t)view * sp.n_verts;
-    const float2* zw = sp.zw + (size_t)view * sp.n_verts;
+    const float* zp = sp.z + (size_t)view * sp.n_verts;
 
     // Software pipeline over the tile's list: reference -> indices -> vertices are three dependent
     // loads, so while one triangle is rasterised the vertices of the next one, the indices of the one
@@ -678,7 +720,7 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
         Fetched f{};
         if (t != kNoTri) {
             f.a0 = xy[i0]; f.a1 = xy[i1]; f.a2 = xy[i2];
-            f.z0 = zw[i0].x; f.z1 = zw[i1].x; f.z2 = zw[i2].x;
+            f.z0 = zp[i0]; f.z1 = zp[i1]; f.z2 = zp[i2];
         }
         return f;
     };
@@ -1109,7 +1151,9 @@ struct FragParams {
     ShadeTables tab;
     uint32_t view0;            // first view of this pass inside the target
     uint32_t paired;           // 1: the metallic and roughness maps have the same size and sampler state, so one set of footprints serves both
-    BlockFlags flags;          // written here, read by the next draw's begin_pass_kernel
+    BlockFlags flags;          // written here, read by the start of the next draw
+    PassReport report;         // host_counters != null: the first workgroup reports the counters of the pass to the host (a lean
+                               // draw, which has no scan kernel to do it)
 };
 
 // shades triangle `tri` at pixel (x,y): packed B,G,R,A.  The window-space vertices are recomputed from
@@ -1233,8 +1277,23 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
 constexpr uint32_t kFragBlockW = kFlagBlockW, kFragBlockH = kFlagBlockH;   // one flag per workgroup of the shading pass
 static_assert(kFragBlockW * kFragBlockH == 256, "the tables of the shading kernel are filled by 256 work-items");
 
+// the counters of the pass, as the scan kernel reports them (every kernel that writes them has finished); one wave
+__device__ inline void report_pass(const PassReport& r, uint32_t lane)
+{
+    static_assert(kMicroSpread == 64, "one counter per lane");
+    uint32_t micro = r.micro_spread[lane * kMicroSpreadStride];
+    for (int o = 32; o > 0; o >>= 1) micro += (uint32_t)__shfl_down((int)micro, o);
+    if (lane == 0) {
+        uint32_t binned = 0;
+        for (uint32_t v = 0; v < r.n_views; ++v) binned += r.pending_total[v];
+        uint32_t* h = r.host_counters;
+        h[0] = 0u; h[1] = 0u; h[2] = r.counters[kCtrUnprojectable]; h[3] = binned; h[4] = micro;
+        h[5] = r.counters[kCtrClipListed]; h[6] = r.counters[kCtrClipped];
+    }
+}
+
 template <int S, bool ANISO, bool IDENT>
-__global__ __launch_bounds__(256) SR_FRAG_ATTR void fragment_kernel(FragParams p)
+__device__ __forceinline__ void fragment_body(const FragParams& p)
 {
     __shared__ float s_dec[256];
     __shared__ float s_thr[256];
@@ -1309,6 +1368,19 @@ __global__ __launch_bounds__(256) SR_FRAG_ATTR void fragment_kernel(FragParams p
         }
     }
     p.color[pix] = outc;
+}
+
+template <int S, bool ANISO, bool IDENT>
+__global__ __launch_bounds__(256) SR_FRAG_ATTR void fragment_kernel(FragParams p)
+{
+    fragment_body<S, ANISO, IDENT>(p);
+}
+// the same, for a lean draw: the launch's first workgroup reports the counters of the pass before it turns to its pixels
+template <int S, bool ANISO, bool IDENT>
+__global__ __launch_bounds__(256) SR_FRAG_ATTR void fragment_report_kernel(FragParams p)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.y * blockDim.x + threadIdx.x < 64u) report_pass(p.report, lane_id());
+    fragment_body<S, ANISO, IDENT>(p);
 }
 
 // =================================================================================================
@@ -1391,13 +1463,33 @@ void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* 
     split_positions_kernel<<<div_up(n, 256), 256, 0, st>>>((const float4*)aos, n, px, py, pz);
 }
 
+static BeginWork make_begin_work(uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0, uint32_t n_views, void* zero16, size_t zero_bytes)
+{
+    BeginWork w;
+    w.vis = (unsigned long long*)vis; w.flags = flags; w.rw = g.rw; w.rh = g.rh; w.S = g.samples; w.view0 = view0; w.n_views = n_views;
+    w.zero4 = (uint4*)zero16; w.n_zero4 = zero_bytes / 16;
+    return w;
+}
+
 void launch_begin_pass(hipStream_t st, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0, uint32_t n_views,
                        void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes)
 {
-    static_assert(kFlagBlockW == 32 && kFlagBlockH == 8, "begin_pass_kernel covers two 32 x 8 flag blocks per workgroup");
-    const dim3 grid(div_up((uint32_t)g.rw, 64), div_up((uint32_t)g.rh, 8), std::max(n_views, 1u));
-    begin_pass_kernel<<<grid, 256, 0, st>>>((unsigned long long*)vis, flags, g.rw, g.rh, g.samples, view0,
-                                            (uint4*)zero16, zero_bytes / 16, (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
+    const size_t items = (size_t)((g.rw + 1) / 2) * g.rh * n_views;
+    const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>((items + 255) / 256, 1), 65536);
+    begin_pass_kernel<<<blocks, 256, 0, st>>>(make_begin_work(vis, flags, g, view0, n_views, zero16, zero_bytes),
+                                              (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
+}
+
+bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* host_views, uint32_t n_views,
+                             ViewXform* views_dst, int W, int H, const ScreenPlanes& out, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0,
+                             void* zero16, size_t zero_bytes)
+{
+    if (!n || !n_views || n_views > kMaxPackedViews) return false;
+    ViewPack pack;
+    std::memcpy(pack.v, host_views, (size_t)n_views * sizeof(ViewXform));
+    vertex_begin_kernel<<<dim3(div_up(n, 256), n_views), 256, 0, st>>>(px, py, pz, n, pack, views_dst, W, H, out,
+                                                                       make_begin_work(vis, flags, g, view0, n_views, zero16, zero_bytes));
+    return true;
 }
 
 void launch_store_views(hipStream_t st, const ViewXform* host_views, uint32_t n, ViewXform* dst)
@@ -1445,7 +1537,7 @@ void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, cons
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters)
 {
     scan_kernel<<<1, 1024, 0, st>>>(b.count_small, b.count_large, n_entries, b.tile_offset, b.counters, b.pending_total, n_views,
-                                    b.block_micro, n_views * b.n_setup_blocks, host_counters);
+                                    b.micro_spread, host_counters);
 }
 
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views)
@@ -1483,24 +1575,31 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
     FragParams p;
     p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
     p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness;
-    p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.flags = f.flags;
+    p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.flags = f.flags; p.report = f.report;
     const TexDesc &m = f.metallic, &r = f.roughness;
     p.paired = m.w == r.w && m.h == r.h && m.levels == r.levels && m.min_lod == r.min_lod && m.max_lod == r.max_lod && m.bias == r.bias &&
                std::memcmp(m.level_off, r.level_off, sizeof m.level_off) == 0;
     const dim3 grid(div_up((uint32_t)f.g.rw, kFragBlockW), div_up((uint32_t)f.g.rh, kFragBlockH), f.n_views), block(kFragBlockW, kFragBlockH);
     // the anisotropic footprint is compiled in only when a bound sampler asks for it
     const bool aniso = f.albedo.max_aniso > 1.0f || f.metallic.max_aniso > 1.0f || f.roughness.max_aniso > 1.0f;
+    const bool report = f.report.host_counters != nullptr;
+#define SR_LAUNCH_FRAGMENT(S, A, I)                                                          \
+    do {                                                                                      \
+        if (report) fragment_report_kernel<S, A, I><<<grid, block, 0, st>>>(p);               \
+        else fragment_kernel<S, A, I><<<grid, block, 0, st>>>(p);                             \
+    } while (0)
     if (f.g.samples == 1) {
-        if (aniso && f.identity_model) fragment_kernel<1, true, true><<<grid, block, 0, st>>>(p);
-        else if (aniso) fragment_kernel<1, true, false><<<grid, block, 0, st>>>(p);
-        else if (f.identity_model) fragment_kernel<1, false, true><<<grid, block, 0, st>>>(p);
-        else fragment_kernel<1, false, false><<<grid, block, 0, st>>>(p);
+        if (aniso && f.identity_model) SR_LAUNCH_FRAGMENT(1, true, true);
+        else if (aniso) SR_LAUNCH_FRAGMENT(1, true, false);
+        else if (f.identity_model) SR_LAUNCH_FRAGMENT(1, false, true);
+        else SR_LAUNCH_FRAGMENT(1, false, false);
     } else {
-        if (aniso && f.identity_model) fragment_kernel<4, true, true><<<grid, block, 0, st>>>(p);
-        else if (aniso) fragment_kernel<4, true, false><<<grid, block, 0, st>>>(p);
-        else if (f.identity_model) fragment_kernel<4, false, true><<<grid, block, 0, st>>>(p);
-        else fragment_kernel<4, false, false><<<grid, block, 0, st>>>(p);
+        if (aniso && f.identity_model) SR_LAUNCH_FRAGMENT(4, true, true);
+        else if (aniso) SR_LAUNCH_FRAGMENT(4, true, false);
+        else if (f.identity_model) SR_LAUNCH_FRAGMENT(4, false, true);
+        else SR_LAUNCH_FRAGMENT(4, false, false);
     }
+#undef SR_LAUNCH_FRAGMENT
 }
 
 void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh)

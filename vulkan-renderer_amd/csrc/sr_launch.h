@@ -17,6 +17,7 @@ struct FragLaunch {
     const float* thresh;
     uint32_t view0, n_views;
     BlockFlags flags;          // of the target
+    PassReport report;         // host_counters != null: the shading pass reports the counters of the pass (lean draws)
     bool identity_model;       // the model matrix of every one of these views is the identity
 };
 
@@ -30,6 +31,12 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
 // zero16/zero_bytes: 16-byte aligned block to zero; views_*: optional 16-byte aligned copy (0 bytes = none)
 void launch_begin_pass(hipStream_t st, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0, uint32_t n_views,
                        void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes);
+// the start of a pass and its vertex stage in one launch, the transforms of the pass's views (host memory) travelling as
+// kernel arguments and being left in views_dst for the later kernels.  Returns false, having launched nothing, when
+// that does not apply (no vertices, or more than kMaxPackedViews views): the caller then uses launch_begin_pass + launch_vertex.
+bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* host_views, uint32_t n_views,
+                             ViewXform* views_dst, int W, int H, const ScreenPlanes& out, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0,
+                             void* zero16, size_t zero_bytes);
 // triangle set-up (micro-triangles resolved, clip list and pending lists filled) followed by the binning of the pending lists
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0,
