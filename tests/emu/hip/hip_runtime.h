@@ -187,6 +187,8 @@ template <class T> __attribute__((always_inline)) static inline T __shfl_up(T v,
     return hipemu_shfl_abs(v, me >= (int)delta ? me - (int)delta : me, line);
 }
 
+static inline int __mul24(int a, int b) { return (int)((uint32_t)((int32_t)((uint32_t)a << 8) >> 8) * (uint32_t)((int32_t)((uint32_t)b << 8) >> 8)); }   // low 32 bits of the product of the low 24 bits, sign-extended
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }

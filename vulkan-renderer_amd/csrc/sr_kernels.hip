@@ -133,13 +133,14 @@ __device__ inline uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __b
 // writes one record per pair that already knows its final position.  The scan then only has to turn
 // per-tile totals into offsets and the fill pass is a plain scatter.
 #ifndef SR_SETUP_TRIS
-#define SR_SETUP_TRIS 4
+#define SR_SETUP_TRIS 3
 #endif
 // Build-time tuning knobs (tools/exp_build.py builds variants of the library with them for A/B runs on the GPU; the
-// defaults are what was measured best): triangles per lane of the set-up kernel (measured on the 10 M-triangle frame:
-// 1 -> 210 us, 2 -> 131 us, 3 -> 82 us, 4 -> 83 us, 6 -> 88 us, 8 -> 97 us: what counts is the number of independent
-// gathers a lane has in flight, until the registers they need cost occupancy; gathering the depths together with the
-// positions, instead of only for triangles that cover a sample, gained nothing: 86 us), and optional occupancy targets (waves per SIMD) that make the compiler fit the set-up / shading kernel into fewer registers.
+// defaults are what was measured best): triangles per lane of the set-up kernel (measured on the 10 M-triangle frame with the
+// depths gathered and the samples resolved by the lane that set the triangle up: 1 -> 210 us, 2 -> 131 us, 3 -> 82 us,
+// 4 -> 83 us, 6 -> 88 us, 8 -> 97 us -- what counts is the number of independent gathers a lane has in flight, until the
+// registers they need cost occupancy; with the covered triangles queued for a second phase: 3 -> 77.8 us, 4 -> 78.0 us,
+// 6 -> 79 us, 8 -> 81 us, and the 50 M-triangle view batch 22.3 instead of 29.1 ms), and optional occupancy targets (waves per SIMD) that make the compiler fit the set-up / shading kernel into fewer registers.
 #ifdef SR_SETUP_WAVES
 #define SR_SETUP_ATTR __attribute__((amdgpu_waves_per_eu(SR_SETUP_WAVES, SR_SETUP_WAVES)))
 #else
@@ -194,11 +195,16 @@ __device__ inline MicroEdges micro_edges(const int2& v0, const int2& v1, const i
     e.bias_c = is_top_left(e.bx - e.ax, e.by - e.ay) ? 0 : -1;
     return e;
 }
+// Product of two factors of the edge functions of a triangle whose box is under 64 pixels (each below 2^15, the product
+// below 2^31).  (The 24-bit multiplier, __mul24, would be exact here too; measured, it made the set-up kernel 13 % longer in
+// instructions and no faster, and the 32-bit tile path 16 % slower.)
+__device__ inline int32_t mul_small(int32_t a, int32_t b) { return a * b; }
+
 __device__ inline void micro_eval(const MicroEdges& e, int32_t px, int32_t py, int32_t& Ea, int32_t& Eb, int32_t& Ec)
 {
-    Ea = (e.cx - e.bx) * (py - e.by) - (e.cy - e.by) * (px - e.bx);
-    Eb = (e.ax - e.cx) * (py - e.cy) - (e.ay - e.cy) * (px - e.cx);
-    Ec = (e.bx - e.ax) * (py - e.ay) - (e.by - e.ay) * (px - e.ax);
+    Ea = mul_small(e.cx - e.bx, py - e.by) - mul_small(e.cy - e.by, px - e.bx);
+    Eb = mul_small(e.ax - e.cx, py - e.cy) - mul_small(e.ay - e.cy, px - e.cx);
+    Ec = mul_small(e.bx - e.ax, py - e.ay) - mul_small(e.by - e.ay, px - e.ax);
 }
 // bit ((j*npx + i)*S + s) set when sample s of pixel (x0+i, y0+j) is covered.  Edge functions are
 // stepped incrementally (exact in integers) from their value at the box's first pixel.
@@ -252,8 +258,8 @@ __device__ inline void micro_resolve(const MicroEdges& e, uint32_t cov, int x0, 
 }
 
 // Set-up: one lane handles kSetupTris triangles (all index loads first, then all vertex loads, so
-// a dozen independent gathers are in flight per lane).  Back faces, degenerate triangles and boxes
-// that contain no sample point are dropped; micro-triangles are resolved on the spot; triangles with
+// nine independent gathers are in flight per lane).  Back faces, degenerate triangles and boxes
+// that contain no sample point are dropped; micro-triangles are resolved here, in a second phase; triangles with
 // one or two vertices that cannot be projected go on the clip list; whatever is left is handed to the
 // binning kernel through the view's pending list (ballots and prefix counts inside the block, one
 // atomic add per block that has any).
@@ -288,19 +294,22 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     for (uint32_t k = 0; k < kSetupTris; ++k) {
         micro_cov[k] = 0; micro_box[k] = 0; pend[k] = false;
         const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
-        // (differences in unsigned arithmetic: x is INT32_MIN for a vertex that cannot be projected -- the area is not used then, but
-        // the subtraction must not overflow a signed int)
-        const int64_t area2 = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
-                              (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y);
+        const int mnx = min(r0[k].x, min(r1[k].x, r2[k].x)), mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
+        const int mny = min(r0[k].y, min(r1[k].y, r2[k].y)), mxy = max(r0[k].y, max(r1[k].y, r2[k].y));
+        // facing: the sign of the doubled area.  A box under 64 pixels on both axes (differences in unsigned arithmetic: x is INT32_MIN
+        // for a vertex that cannot be projected) keeps every factor below 2^15: the 24-bit multiplier is exact; else 64 bits.
+        const bool small_box = (uint32_t)mxx - (uint32_t)mnx < 16384u && (uint32_t)mxy - (uint32_t)mny < 16384u;
+        bool front;
+        if (small_box) front = mul_small(r1[k].x - r0[k].x, r2[k].y - r0[k].y) - mul_small(r2[k].x - r0[k].x, r1[k].y - r0[k].y) < 0;
+        else front = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
+                     (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y) < 0;
         if (in_range[k] && bad > 0 && bad < 3) {
             // needs the near-plane clipper; a full list drops and counts the triangle
             const uint32_t slot = atomicAdd(&b.counters[kCtrClipListed], 1u);
             if (slot < clip.capacity) clip.entries[slot] = make_uint2(view, tri[k]);
             else ++n_unproj;
         }
-        if (in_range[k] && bad == 0 && area2 < 0) {
-            const int mnx = min(r0[k].x, min(r1[k].x, r2[k].x)), mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
-            const int mny = min(r0[k].y, min(r1[k].y, r2[k].y)), mxy = max(r0[k].y, max(r1[k].y, r2[k].y));
+        if (in_range[k] && bad == 0 && front) {
             int x0, x1, y0, y1;
             pixel_span<S>(mnx, mxx, x0, x1);
             pixel_span<S>(mny, mxy, y0, y1);
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
             const int npx = x1 - x0 + 1, npy = y1 - y0 + 1;
             if (npx > 0 && npy > 0) {
-                if (npx * npy <= micro_pixels<S>() && mxx - mnx < 16384 && mxy - mny < 16384) {
+                if (npx * npy <= micro_pixels<S>() && small_box) {
                     micro_cov[k] = micro_coverage<S>(micro_edges(r0[k], r1[k], r2[k]), x0, y0, npx, npy);
                     micro_box[k] = (uint32_t)x0 | ((uint32_t)y0 << 14) | ((uint32_t)(npx - 1) << 28);
                     if (micro_cov[k]) ++n_micro;
@@ -316,22 +325,40 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             }
         }
     }
-    // micro-triangles with a covered sample: fetch the three depths (all loads first), then resolve
+    // Micro-triangles with a covered sample are queued in LDS and resolved in a second, dense phase: a work-item per
+    // queued triangle fetches its indices, positions and depths again (cache hits: the workgroup touched those lines a
+    // moment ago) and does the atomic mins.  The first phase then carries neither depths nor the resolve code in its
+    // registers, and the second runs with every lane busy instead of the one lane in two or three that holds a covered
+    // triangle.
+    __shared__ uint32_t s_q_tri[kSetupBlockTris], s_q_cov[kSetupBlockTris], s_q_box[kSetupBlockTris];
+    __shared__ uint32_t s_q_count;
+    if (tid == 0) s_q_count = 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kSetupTris; ++k) {
+        const bool queued = micro_cov[k] != 0u;
+        const uint64_t mask = __ballot(queued);
+        uint32_t base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&s_q_count, (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (queued) {
+            const uint32_t q = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            s_q_tri[q] = tri[k]; s_q_cov[q] = micro_cov[k]; s_q_box[q] = micro_box[k];
+        }
+    }
+    __syncthreads();
     {
         const float* zp = sp.z + (size_t)view * sp.n_verts;
         unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
-        float z0[kSetupTris], z1[kSetupTris], z2[kSetupTris];
-#pragma unroll
-        for (uint32_t k = 0; k < kSetupTris; ++k) {
-            z0[k] = z1[k] = z2[k] = 0.0f;
-            if (micro_cov[k]) { z0[k] = zp[i0[k]]; z1[k] = zp[i1[k]]; z2[k] = zp[i2[k]]; }
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kSetupTris; ++k) {
-            if (!micro_cov[k]) continue;
-            const int32_t A = -((r1[k].x - r0[k].x) * (r2[k].y - r0[k].y) - (r2[k].x - r0[k].x) * (r1[k].y - r0[k].y));
-            micro_resolve<S>(micro_edges(r0[k], r1[k], r2[k]), micro_cov[k], (int)(micro_box[k] & 16383u), (int)((micro_box[k] >> 14) & 16383u),
-                             (int)(micro_box[k] >> 28) + 1, z0[k], z1[k], z2[k], 1.0f / (float)A, tri[k], vis_view, g);
+        const uint32_t n_q = s_q_count;
+        for (uint32_t q = tid; q < n_q; q += 256u) {
+            const uint32_t t = s_q_tri[q], cov = s_q_cov[q], box = s_q_box[q];
+            const uint32_t j0 = idx[3 * (size_t)t], j1 = idx[3 * (size_t)t + 1], j2 = idx[3 * (size_t)t + 2];
+            const int2 a0 = xy[j0], a1 = xy[j1], a2 = xy[j2];
+            const float za = zp[j0], zb = zp[j1], zc = zp[j2];
+            const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
+            micro_resolve<S>(micro_edges(a0, a1, a2), cov, (int)(box & 16383u), (int)((box >> 14) & 16383u), (int)(box >> 28) + 1,
+                             za, zb, zc, 1.0f / (float)A, t, vis_view, g);
         }
     }
     if (n_unproj) atomicAdd(&b.counters[kCtrUnprojectable], n_unproj);   // rare
@@ -666,9 +693,9 @@ __device__ inline void raster_pixel32(const TriSetup& ts, uint32_t tri, int x, i
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int32_t px = x * kSubpix + sample_dx(S, s), py = y * kSubpix + sample_dy(S, s);
-        const int32_t Ea = (ts.cx - ts.bx) * (py - ts.by) - (ts.cy - ts.by) * (px - ts.bx);
-        const int32_t Eb = (ts.ax - ts.cx) * (py - ts.cy) - (ts.ay - ts.cy) * (px - ts.cx);
-        const int32_t Ec = (ts.bx - ts.ax) * (py - ts.ay) - (ts.by - ts.ay) * (px - ts.ax);
+        const int32_t Ea = mul_small(ts.cx - ts.bx, py - ts.by) - mul_small(ts.cy - ts.by, px - ts.bx);
+        const int32_t Eb = mul_small(ts.ax - ts.cx, py - ts.cy) - mul_small(ts.ay - ts.cy, px - ts.cx);
+        const int32_t Ec = mul_small(ts.bx - ts.ax, py - ts.ay) - mul_small(ts.by - ts.ay, px - ts.ax);
         if (((Ea + ts.bias_a) | (Eb + ts.bias_b) | (Ec + ts.bias_c)) < 0) continue;
         const float l0 = (float)Ea * ts.rA, l2 = (float)Eb * ts.rA, l1 = (float)Ec * ts.rA;
         float z = fmaf(l2, ts.z2, fmaf(l1, ts.z1, l0 * ts.z0));
