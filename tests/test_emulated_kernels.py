@@ -41,7 +41,7 @@ def build_emulation_library():
 
 # device-level knobs under which every frame must stay the same: smaller tiles, a tile reference list that overflows on
 # every first frame, a scratch budget that splits batches into passes
-KNOBS = [dict(SR_TILE_LOG2="5"), dict(SR_REF_CAPACITY="16"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4")]
+KNOBS = [dict(SR_TILE_LOG2="5", SR_FILL_BLOCKS="1"), dict(SR_REF_CAPACITY="16"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4")]
 _child_runs = {}
 
 

@@ -472,6 +472,31 @@ def test_view_batch_split_into_passes(sr, oracle, device, samples):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
+def test_workgroups_that_take_every_view_of_a_pass(sr, oracle, device, samples):
+    """A large mesh drawn for a batch of views: the vertex and set-up kernels load positions and indices once and go
+    through the views of the pass one after the other.  SR_FILL_BLOCKS=1 makes them do so for a small mesh too (by
+    default its views would be spread over more workgroups).  11 views (more than travel as kernel arguments, so the
+    batch form of the vertex kernel runs) of a soup with micro-triangles, large triangles and near-plane crossings."""
+    verts, idx = util.random_soup(4000, seed=23, size=0.3)
+    n_views, W, H = 11, 200, 120
+    ubos = sr.scene.orbit_ubos(n_views, W, H)
+    ubos[3] = sr.scene.default_camera_ubo(W, H, eye=(0.1, 0.05, 0.02))   # inside the cloud: triangles through the near plane
+    images = sr.scene.material_textures(16)
+    dev = util.device_with_env(sr, SR_FILL_BLOCKS="1")
+    try:
+        got = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, samples)
+        for k in range(n_views):
+            ref = oracle.draw(ubos[k], verts, idx, images, W, H, samples)
+            _check_view(got[k], ref, check_color=int((ref["tri"] != sr.NO_TRIANGLE).any(axis=-1).sum()) >= 2000)
+        spread = util.gpu_render(sr, device, verts, idx, images, ubos, W, H, samples)
+        assert spread[0]["stats"] == got[0]["stats"]
+        for a, b in zip(got, spread):
+            assert np.array_equal(a["vis"], b["vis"]) and np.array_equal(a["bgra"], b["bgra"])
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("samples", [1, 4])
 def test_screen_split_is_partition_independent(sr, oracle, device, samples):
     """Sort-first building block: a target restricted to a rectangle stores exactly the crop of the
     full frame, for rectangles that cut through tiles and pixels quads."""

@@ -73,6 +73,7 @@ struct sr_device_t {
     DeviceBuffer screen, tile_count, tile_offset, records, pending, refs, views;
     DeviceBuffer clip;           // entries of the near-plane clip list: capacity x 8 bytes
     uint32_t clip_capacity = 65536;   // triangles per pass that can be clipped; more are dropped and counted
+    uint32_t fill_blocks = kFillBlocks;   // see sr_launch.h
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
     struct Staging { ViewXform* h = nullptr; void* d = nullptr; size_t cap = 0 /* bytes */; hipEvent_t ev = nullptr; bool in_flight = false; };   // h: pinned + mapped, d: its device address
@@ -166,7 +167,7 @@ int choose_tile_log2(const sr_device_t* dev, int samples)
 // per-view scratch bytes of a pass
 size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g)
 {
-    return (size_t)m->n_verts * sizeof(ScreenVertex) + ((size_t)m->n_tris + 1024) * (4 * sizeof(BinRecord) + 4) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 16 + 64;
+    return (size_t)plane_stride(m->n_verts) * sizeof(ScreenVertex) + ((size_t)m->n_tris + 1024) * (4 * sizeof(BinRecord) + 4) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 16 + 64;
 }
 
 uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views)
@@ -205,7 +206,8 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     // spread micro-triangle counters] (zeroed at the start of every pass, padded to 16 bytes) [block_count: written by the binning kernel]
     const size_t zero_words = (count_words + vpp + kNumPassCounters + kMicroSpread * kMicroSpreadStride + 3) & ~(size_t)3;
     const size_t view_bytes = (size_t)n_views * sizeof(ViewXform);
-    const size_t bytes_screen = (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(ScreenVertex);
+    const uint32_t v_stride = std::max<uint32_t>(plane_stride(m->n_verts), 4);
+    const size_t bytes_screen = (size_t)vpp * v_stride * sizeof(ScreenVertex);   // (12 of the 16 bytes are used: int2 plane, float plane)
     const size_t bytes_tile_count = (zero_words + (size_t)vpp * n_blocks) * 4;
     const size_t bytes_pending = (size_t)vpp * pending_stride * 4;
     const size_t bytes_tile_offset = ((size_t)vpp * n_tiles + 1) * 4;
@@ -275,8 +277,8 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
 
     ScreenPlanes sp{};
     sp.xy = (int2*)ps.screen;
-    sp.z = (float*)((char*)ps.screen + (size_t)vpp * std::max<uint32_t>(m->n_verts, 1) * sizeof(int2));
-    sp.n_verts = m->n_verts;
+    sp.z = (float*)((char*)ps.screen + (size_t)vpp * v_stride * sizeof(int2));
+    sp.stride = v_stride;
     BinBuffers b{};
     b.count_small = ps.tile_count;
     b.count_large = b.count_small + (size_t)vpp * n_tiles;
@@ -318,9 +320,9 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
             if (copy_views) { SR_HIP(hipEventRecord(staging->ev, st)); staging->in_flight = true; }
         }
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
-        if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr);
+        if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr, dev->fill_blocks);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, !tg->lean);
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, !tg->lean, dev->fill_blocks);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
@@ -456,6 +458,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* v = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 30;
     if (const char* v = std::getenv("SR_REF_CAPACITY")) dev->ref_capacity = (uint64_t)std::max(1, std::atoi(v));   // initial size of the tile reference list (tests: force the grow-and-redraw path)
     if (const char* v = std::getenv("SR_CLIP_CAPACITY")) dev->clip_capacity = (uint32_t)std::max(1, std::atoi(v));   // tests: a full clip list
+    if (const char* v = std::getenv("SR_FILL_BLOCKS")) dev->fill_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = a workgroup always takes all views
     if (const char* v = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 20;   // small budgets: many passes per draw
     *out = dev;
     return SR_OK;
@@ -504,10 +507,11 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
     m->n_verts = n_vertices; m->n_tris = n_tris;
     const size_t nv = std::max<uint32_t>(n_vertices, 1), ni = std::max<uint32_t>(n_tris * 3, 1);
     hipError_t e = hipMalloc(&m->d_aos, nv * 32);
-    if (e == hipSuccess) e = hipMalloc((void**)&m->px, nv * 12);
+    const size_t ps = std::max<uint32_t>(plane_stride(n_vertices), 4);   // the three position planes, each padded to whole groups of four
+    if (e == hipSuccess) e = hipMalloc((void**)&m->px, ps * 12);
     if (e == hipSuccess) e = hipMalloc((void**)&m->d_idx, ni * 4);
     if (e != hipSuccess) { (void)hipFree(m->d_aos); (void)hipFree(m->px); (void)hipFree(m->d_idx); delete m; SR_HIP(e); }
-    m->py = m->px + nv; m->pz = m->py + nv;
+    m->py = m->px + ps; m->pz = m->py + ps;
     if (n_vertices) e = hipMemcpyAsync(m->d_aos, vertices, (size_t)n_vertices * 32, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess && n_tris) e = hipMemcpyAsync(m->d_idx, indices, (size_t)n_tris * 12, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
@@ -928,12 +932,12 @@ int sr_debug_vertex_stage(sr_device dev, sr_mesh mesh, const void* ubo_block, in
     void *d_view = nullptr, *d_screen = nullptr, *d_clip = nullptr, *d_planes = nullptr;
     hipError_t e = hipMalloc(&d_view, sizeof x);
     if (e == hipSuccess) e = hipMalloc(&d_screen, (size_t)n * 16);
-    if (e == hipSuccess) e = hipMalloc(&d_planes, (size_t)n * 16);
+    if (e == hipSuccess) e = hipMalloc(&d_planes, (size_t)plane_stride(n) * 12);
     if (e == hipSuccess) e = hipMalloc(&d_clip, (size_t)n * 16);
     if (e == hipSuccess) e = hipMemcpy(d_view, &x, sizeof x, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         ScreenPlanes sp{};
-        sp.xy = (int2*)d_planes; sp.z = (float*)((char*)d_planes + (size_t)n * 8); sp.n_verts = n;
+        sp.stride = plane_stride(n); sp.xy = (int2*)d_planes; sp.z = (float*)((char*)d_planes + (size_t)sp.stride * 8);
         launch_vertex(dev->stream, mesh->px, mesh->py, mesh->pz, n, (const ViewXform*)d_view, 1, width, height, sp, (ScreenVertex*)d_screen, (float*)d_clip);
         e = hipStreamSynchronize(dev->stream);
     }

@@ -45,10 +45,13 @@ struct ScreenVertex {    // 16 bytes; rw == 0 marks a vertex that cannot be proj
 // needs through the caches: triangle set-up reads xy only, and z only for the triangles that cover a sample.
 // (1/w is not stored: the shading pass recomputes the vertices it needs from the positions.)
 constexpr int32_t kBadVertexX = INT32_MIN;   // xy.x of a vertex that cannot be projected
+// Vertex planes are padded to whole groups of four vertices, so that the vertex stage can move four vertices per work-item
+// with 16-byte loads and stores whatever the vertex count and the view.
+__host__ __device__ inline uint32_t plane_stride(uint32_t n_verts) { return (n_verts + 3u) & ~3u; }
 struct ScreenPlanes {
-    int2* xy;      // [views][n_verts]: window x, y in 1/256 pixel
-    float* z;      // [views][n_verts]: depth
-    uint32_t n_verts;
+    int2* xy;      // [views][stride]: window x, y in 1/256 pixel
+    float* z;      // [views][stride]: depth
+    uint32_t stride;   // vertices per view in both planes: plane_stride(number of vertices)
 };
 
 struct TexDesc {

@@ -16,8 +16,8 @@ __global__ __launch_bounds__(256) void split_positions_kernel(const float4* __re
                                                               float* __restrict__ px, float* __restrict__ py, float* __restrict__ pz)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float4 a = aos[2 * (size_t)i];
+    if (i >= plane_stride(n)) return;
+    const float4 a = i < n ? aos[2 * (size_t)i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the padding of the planes is zeroed
     px[i] = a.x; py[i] = a.y; pz[i] = a.z;
 }
 
@@ -76,8 +76,48 @@ __global__ __launch_bounds__(64) void store_views_kernel(ViewPack pack, uint32_t
 
 // =================================================================================================
 // stage 1: vertex shader (shaders/shader.vert:20-27) + perspective divide + viewport + snapping
-// one thread per (vertex, view); coalesced 4-byte plane loads, one 16-byte store
+// One work-item per G consecutive vertices, for a range of the views of the launch: the positions are loaded once (one load of
+// G floats from each of the three planes) and projected with one view's transform after the other, so a batch of views reads the
+// mesh once instead of once per view (the 128-view share of the 50 M-triangle batch: 14.4 -> 8.6 ms).  All plane strides are
+// multiples of four vertices; what is computed for the padding of the last group lands in the padding of the output planes and is
+// never read.  Measured on MI355X: G = 4 is the fastest for the one-view frame (fused with the start of the pass: 34 -> 29 us for
+// 5 M vertices), G = 2 for the view batch.
 // =================================================================================================
+constexpr uint32_t kFusedVertexGroup = 4, kBatchVertexGroup = 2;
+template <uint32_t G> struct VecOf;
+template <> struct VecOf<1> { typedef float F; typedef int2 I; };
+template <> struct VecOf<2> { typedef float2 F; typedef int4 I; };
+template <> struct VecOf<4> { typedef float4 F; struct __attribute__((aligned(16))) I { int4 a, b; }; };
+template <uint32_t G, class Views>
+__device__ inline void vertex_group(const Views& views, uint32_t view_begin, uint32_t view_end, const float* __restrict__ px, const float* __restrict__ py,
+                                    const float* __restrict__ pz, uint32_t n, uint32_t group, int W, int H, const ScreenPlanes& out,
+                                    ScreenVertex* __restrict__ debug_out, float4* __restrict__ clip_out)
+{
+    typedef typename VecOf<G>::F FV;
+    typedef typename VecOf<G>::I IV;
+    if (G * group >= n) return;
+    union { FV v; float f[G]; } X, Y, Z;
+    X.v = reinterpret_cast<const FV*>(px)[group]; Y.v = reinterpret_cast<const FV*>(py)[group]; Z.v = reinterpret_cast<const FV*>(pz)[group];
+    for (uint32_t view = view_begin; view < view_end; ++view) {
+        union { IV v; int i[2 * G]; } xy;
+        union { FV v; float f[G]; } z;
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
+            float clip[4];
+            const ScreenVertex sv = project_vertex(views[view], X.f[k], Y.f[k], Z.f[k], W, H, clip);
+            xy.i[2 * k] = sv.rw == 0.0f ? kBadVertexX : sv.X; xy.i[2 * k + 1] = sv.Y; z.f[k] = sv.z;
+            const uint32_t i = G * group + k;
+            if ((debug_out || clip_out) && i < n) {   // (the debugging entry point only)
+                if (debug_out) debug_out[(size_t)view * n + i] = sv;
+                if (clip_out) clip_out[(size_t)view * n + i] = make_float4(clip[0], clip[1], clip[2], clip[3]);
+            }
+        }
+        const size_t o = (size_t)view * out.stride + G * (size_t)group;
+        *reinterpret_cast<IV*>(out.xy + o) = xy.v;
+        *reinterpret_cast<FV*>(out.z + o) = z.v;
+    }
+}
+
 // The start of a pass folded into the vertex kernel (a draw of a few views, whose transforms fit the kernel arguments):
 // the same launch clears the flagged blocks of the visibility buffer, zeroes the binning counters and leaves the
 // transforms in device memory for the later kernels -- its stores ride along with the vertex stage's loads, and the pass
@@ -86,39 +126,23 @@ __global__ __launch_bounds__(256) void vertex_begin_kernel(const float* __restri
                                                            uint32_t n, ViewPack pack, ViewXform* __restrict__ views_dst, int W, int H,
                                                            ScreenPlanes out, BeginWork w)
 {
-    const size_t block_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const size_t gtid = block_id * 256u + threadIdx.x, gstride = (size_t)gridDim.x * gridDim.y * 256u;
-    if (block_id == 0) {
+    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x, gstride = (size_t)gridDim.x * 256u;
+    if (blockIdx.x == 0) {
         constexpr uint32_t kWords = sizeof(ViewXform) / 4;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&pack);
         for (uint32_t i = threadIdx.x; i < w.n_views * kWords; i += 256u) reinterpret_cast<uint32_t*>(views_dst)[i] = src[i];
     }
     begin_work(w, gtid, gstride);
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t view = blockIdx.y;
-    if (i >= n) return;
-    float clip[4];
-    const ScreenVertex sv = project_vertex(pack.v[view], px[i], py[i], pz[i], W, H, clip);
-    const size_t o = (size_t)view * n + i;
-    out.xy[o] = make_int2(sv.rw == 0.0f ? kBadVertexX : sv.X, sv.Y);
-    out.z[o] = sv.z;
+    vertex_group<kFusedVertexGroup>(pack.v, 0u, w.n_views, px, py, pz, n, blockIdx.x * 256u + threadIdx.x, W, H, out, nullptr, nullptr);
 }
 
 __global__ __launch_bounds__(256) void vertex_kernel(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                     uint32_t n, const ViewXform* __restrict__ views, int W, int H,
-                                                     ScreenPlanes out, ScreenVertex* __restrict__ debug_out, float4* __restrict__ clip_out)
+                                                     uint32_t n, const ViewXform* __restrict__ views, uint32_t n_views, uint32_t views_per_block,
+                                                     int W, int H, ScreenPlanes out, ScreenVertex* __restrict__ debug_out, float4* __restrict__ clip_out)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t view = blockIdx.y;
-    if (i >= n) return;
-    const ViewXform& vx = views[view];
-    float clip[4];
-    const ScreenVertex sv = project_vertex(vx, px[i], py[i], pz[i], W, H, clip);
-    const size_t o = (size_t)view * n + i;
-    out.xy[o] = make_int2(sv.rw == 0.0f ? kBadVertexX : sv.X, sv.Y);
-    out.z[o] = sv.z;
-    if (debug_out) debug_out[o] = sv;
-    if (clip_out) clip_out[o] = make_float4(clip[0], clip[1], clip[2], clip[3]);
+    const uint32_t view_begin = blockIdx.y * views_per_block;
+    vertex_group<kBatchVertexGroup>(views, view_begin, min(view_begin + views_per_block, n_views), px, py, pz, n, blockIdx.x * 256u + threadIdx.x, W, H,
+                                    out, debug_out, clip_out);
 }
 
 // =================================================================================================
@@ -250,11 +274,27 @@ __device__ inline void micro_resolve(const MicroEdges& e, uint32_t cov, int x0, 
             const float l0 = (float)Ea * rA, l2 = (float)Eb * rA, l1 = (float)Ec * rA;
             float z = fmaf(l2, z2, fmaf(l1, z1, l0 * z0));
             z = z + 0.0f;
-            if (z >= 0.0f && z < 1.0f)
-                atomicMin(&vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S + s], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri;
+            if (z >= 0.0f && z < 1.0f) atomicMin(&vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S + s], key);
         }
         if (++i == npx) { i = 0; ++j; }
     }
+}
+
+// The hardware deals workgroups to the eight XCDs round robin by linear workgroup id, and every XCD has an L2 of its own.  Neighbouring
+// parts of a mesh share vertices and land on neighbouring pixels, so with the plain order every vertex line is fetched by several
+// L2s and the lines of the visibility buffer travel between them under the atomic mins.  xcd_runs renumbers the workgroups so that
+// each XCD works through runs of kXcdRun consecutive logical ids (short enough that the eight stay evenly loaded).  A bijection on
+// [0, n): the ids past the last whole group of 8 * kXcdRun keep their number.
+#ifndef SR_XCD_RUN
+#define SR_XCD_RUN 64
+#endif
+constexpr uint32_t kXcdRun = SR_XCD_RUN;
+__device__ inline uint32_t xcd_runs(uint32_t b, uint32_t n)
+{
+    if (kXcdRun <= 1u || b >= n / (8u * kXcdRun) * (8u * kXcdRun)) return b;
+    const uint32_t x = b & 7u, j = b >> 3;
+    return ((j / kXcdRun) * 8u + x) * kXcdRun + j % kXcdRun;
 }
 
 // Set-up: one lane handles kSetupTris triangles (all index loads first, then all vertex loads, so
@@ -263,17 +303,19 @@ __device__ inline void micro_resolve(const MicroEdges& e, uint32_t cov, int x0, 
 // one or two vertices that cannot be projected go on the clip list; whatever is left is handed to the
 // binning kernel through the view's pending list (ballots and prefix counts inside the block, one
 // atomic add per block that has any).
-template <int S>
+template <int S, bool VIEW_LOOP>
 __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
-                                                    FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, uint32_t view0)
+                                                    FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, uint32_t view0,
+                                                    uint32_t n_views, uint32_t views_per_block)
 {
     __shared__ uint32_t s_wave[kSetupTris * 4];
     __shared__ uint32_t s_micro[4];
     __shared__ uint32_t s_base;
-    const uint32_t view = blockIdx.y;
+    __shared__ uint32_t s_q_tri[kSetupBlockTris], s_q_cov[kSetupBlockTris], s_q_box[kSetupBlockTris];
+    __shared__ uint32_t s_q_count;
+    const uint32_t turn = xcd_runs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const uint32_t blk = turn % gridDim.x, view_begin = turn / gridDim.x * views_per_block;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const uint32_t blk = blockIdx.x;
-    const int2* xy = sp.xy + (size_t)view * sp.n_verts;
     uint32_t tri[kSetupTris], i0[kSetupTris], i1[kSetupTris], i2[kSetupTris];
     bool in_range[kSetupTris];
 #pragma unroll
@@ -283,6 +325,13 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
         const uint32_t tt = in_range[k] ? tri[k] : 0u;
         i0[k] = idx[3 * (size_t)tt]; i1[k] = idx[3 * (size_t)tt + 1]; i2[k] = idx[3 * (size_t)tt + 2];
     }
+    // the indices are loaded once for all the views the workgroup handles (every view of a pass, unless the mesh is small): a batch of
+    // views streams the index list once instead of once per view
+    // (VIEW_LOOP false = one view per workgroup: without the loop around it the code needs 63 registers instead of 90, which is worth
+    // 5 % on a one-view frame of 10 M triangles)
+    const uint32_t view_end = VIEW_LOOP ? min(view_begin + views_per_block, n_views) : view_begin + 1u;
+    for (uint32_t view = view_begin; view < view_end; ++view) {
+    const int2* xy = sp.xy + (size_t)view * sp.stride;
     int2 r0[kSetupTris], r1[kSetupTris], r2[kSetupTris];
 #pragma unroll
     for (uint32_t k = 0; k < kSetupTris; ++k) { r0[k] = xy[i0[k]]; r1[k] = xy[i1[k]]; r2[k] = xy[i2[k]]; }
@@ -330,8 +379,6 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     // moment ago) and does the atomic mins.  The first phase then carries neither depths nor the resolve code in its
     // registers, and the second runs with every lane busy instead of the one lane in two or three that holds a covered
     // triangle.
-    __shared__ uint32_t s_q_tri[kSetupBlockTris], s_q_cov[kSetupBlockTris], s_q_box[kSetupBlockTris];
-    __shared__ uint32_t s_q_count;
     if (tid == 0) s_q_count = 0u;
     __syncthreads();
 #pragma unroll
@@ -348,7 +395,7 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     }
     __syncthreads();
     {
-        const float* zp = sp.z + (size_t)view * sp.n_verts;
+        const float* zp = sp.z + (size_t)view * sp.stride;
         unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
         const uint32_t n_q = s_q_count;
         for (uint32_t q = tid; q < n_q; q += 256u) {
@@ -356,9 +403,9 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             const uint32_t j0 = idx[3 * (size_t)t], j1 = idx[3 * (size_t)t + 1], j2 = idx[3 * (size_t)t + 2];
             const int2 a0 = xy[j0], a1 = xy[j1], a2 = xy[j2];
             const float za = zp[j0], zb = zp[j1], zc = zp[j2];
+            const int bx0 = (int)(box & 16383u), by0 = (int)((box >> 14) & 16383u), bnpx = (int)(box >> 28) + 1;
             const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
-            micro_resolve<S>(micro_edges(a0, a1, a2), cov, (int)(box & 16383u), (int)((box >> 14) & 16383u), (int)(box >> 28) + 1,
-                             za, zb, zc, 1.0f / (float)A, t, vis_view, g);
+            micro_resolve<S>(micro_edges(a0, a1, a2), cov, bx0, by0, bnpx, za, zb, zc, 1.0f / (float)A, t, vis_view, g);
         }
     }
     if (n_unproj) atomicAdd(&b.counters[kCtrUnprojectable], n_unproj);   // rare
@@ -385,17 +432,20 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
         if (micro) atomicAdd(&b.micro_spread[(blk % kMicroSpread) * kMicroSpreadStride], micro);
         s_base = total ? atomicAdd(&b.pending_total[view], total) : 0u;
     }
-    if (total == 0) return;   // uniform over the block
     __syncthreads();
-    uint32_t* list = b.pending + (size_t)view * b.pending_stride + s_base;
-    uint32_t run = 0;
+    if (total != 0) {   // uniform over the block
+        uint32_t* list = b.pending + (size_t)view * b.pending_stride + s_base;
+        uint32_t run = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kSetupTris; ++k) {
+        for (uint32_t k = 0; k < kSetupTris; ++k) {
 #pragma unroll
-        for (uint32_t w = 0; w < 4; ++w) {
-            if (w == wave && pend[k]) list[run + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))] = tri[k];
-            run += s_wave[k * 4u + w];
+            for (uint32_t w = 0; w < 4; ++w) {
+                if (w == wave && pend[k]) list[run + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))] = tri[k];
+                run += s_wave[k * 4u + w];
+            }
         }
+    }
+    __syncthreads();   // the workgroup's tables are free for the next view
     }
 }
 
@@ -436,7 +486,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
     if (tid == 0) s_total = 0u;
 
     const uint32_t* slice = b.pending + (size_t)view * b.pending_stride + (size_t)blk * kBlockTris;
-    const int2* xy = sp.xy + (size_t)view * sp.n_verts;
+    const int2* xy = sp.xy + (size_t)view * sp.stride;
     uint32_t tri[kTrisPerThread], i0[kTrisPerThread], i1[kTrisPerThread], i2[kTrisPerThread];
     bool have[kTrisPerThread];
 #pragma unroll
@@ -727,8 +777,8 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
 
     for (int i = tid; i < T * T * S; i += TPB) tile[i] = kVisClear;
     __syncthreads();
-    const int2* xy = sp.xy + (size_t)view * sp.n_verts;
-    const float* zp = sp.z + (size_t)view * sp.n_verts;
+    const int2* xy = sp.xy + (size_t)view * sp.stride;
+    const float* zp = sp.z + (size_t)view * sp.stride;
 
     // Software pipeline over the tile's list: reference -> indices -> vertices are three dependent
     // loads, so while one triangle is rasterised the vertices of the next one, the indices of the one
@@ -1487,7 +1537,7 @@ static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b
 void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz)
 {
     if (!n) return;
-    split_positions_kernel<<<div_up(n, 256), 256, 0, st>>>((const float4*)aos, n, px, py, pz);
+    split_positions_kernel<<<div_up(plane_stride(n), 256), 256, 0, st>>>((const float4*)aos, n, px, py, pz);
 }
 
 static BeginWork make_begin_work(uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0, uint32_t n_views, void* zero16, size_t zero_bytes)
@@ -1514,7 +1564,10 @@ bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, c
     if (!n || !n_views || n_views > kMaxPackedViews) return false;
     ViewPack pack;
     std::memcpy(pack.v, host_views, (size_t)n_views * sizeof(ViewXform));
-    vertex_begin_kernel<<<dim3(div_up(n, 256), n_views), 256, 0, st>>>(px, py, pz, n, pack, views_dst, W, H, out,
+    // enough workgroups for the clearing part too when the mesh is small (a workgroup past the last vertex group only clears)
+    const size_t items = (size_t)((g.rw + 1) / 2) * g.rh * n_views;
+    const uint32_t for_clearing = (uint32_t)std::min<size_t>(div_up((uint32_t)std::min<size_t>(items, 1u << 30), 1024u), 4096u);
+    vertex_begin_kernel<<<std::max(div_up(n, kFusedVertexGroup * 256u), for_clearing), 256, 0, st>>>(px, py, pz, n, pack, views_dst, W, H, out,
                                                                        make_begin_work(vis, flags, g, view0, n_views, zero16, zero_bytes));
     return true;
 }
@@ -1528,10 +1581,14 @@ void launch_store_views(hipStream_t st, const ViewXform* host_views, uint32_t n,
 }
 
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
-                   int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out)
+                   int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out, uint32_t fill_blocks)
 {
     if (!n || !n_views) return;
-    vertex_kernel<<<dim3(div_up(n, 256), n_views), 256, 0, st>>>(px, py, pz, n, views, W, H, out, debug_out, (float4*)clip_out);
+    // a workgroup takes every view of the launch for its vertices, unless the mesh is too small to fill the chip that way
+    const uint32_t grid_x = div_up(n, kBatchVertexGroup * 256u);
+    const uint32_t views_per_block = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views);
+    vertex_kernel<<<dim3(grid_x, div_up(n_views, views_per_block)), 256, 0, st>>>(px, py, pz, n, views, n_views, views_per_block, W, H, out, debug_out,
+                                                                                   (float4*)clip_out);
 }
 
 // workgroups of the kernels that walk the pending list in chunks: enough to fill the chip when the list is long, few
@@ -1539,12 +1596,20 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
 static inline uint32_t chunk_grid(const BinBuffers& b) { return std::min<uint32_t>(std::max<uint32_t>(b.n_blocks, 1u), 1024u); }
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
-                  const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between, bool bin)
+                  const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between, bool bin, uint32_t fill_blocks)
 {
     if (!n_tris || !n_views) return;
-    const dim3 grid(div_up(n_tris, kSetupBlockTris), n_views);
-    if (g.samples == 1) setup_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0);
-    else setup_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0);
+    // a workgroup takes every view of the pass for its triangles, unless the mesh is too small to fill the chip that way
+    const uint32_t grid_x = div_up(n_tris, kSetupBlockTris);
+    const uint32_t views_per_block = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views);
+    const dim3 grid(grid_x, div_up(n_views, views_per_block));
+    if (views_per_block == 1) {
+        if (g.samples == 1) setup_kernel<1, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0, n_views, 1u);
+        else setup_kernel<4, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0, n_views, 1u);
+    } else {
+        if (g.samples == 1) setup_kernel<1, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0, n_views, views_per_block);
+        else setup_kernel<4, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0, n_views, views_per_block);
+    }
     if (between) (void)hipEventRecord(between, st);
     if (!bin) return;
     const dim3 bin_grid(chunk_grid(b), n_views);

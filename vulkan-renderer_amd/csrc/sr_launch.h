@@ -25,8 +25,11 @@ constexpr uint32_t kMaxPackedViews = 8;   // views whose transforms fit the kern
 // writes n (<= kMaxPackedViews) per-view transforms from host memory to dst without any copy or staging buffer
 void launch_store_views(hipStream_t st, const ViewXform* host_views, uint32_t n, ViewXform* dst);
 void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* px, float* py, float* pz);
+// fill_blocks (here and in launch_setup): a workgroup handles its vertices / triangles for EVERY view of the launch, loading positions /
+// indices once -- unless that leaves fewer than about fill_blocks workgroups, in which case the views are spread over more of them
+constexpr uint32_t kFillBlocks = 4096;
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
-                   int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out);
+                   int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out, uint32_t fill_blocks = kFillBlocks);
 // vis: the target's whole visibility buffer, of which the flagged blocks of views [view0, view0 + n_views) are cleared;
 // zero16/zero_bytes: 16-byte aligned block to zero; views_*: optional 16-byte aligned copy (0 bytes = none)
 void launch_begin_pass(hipStream_t st, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0, uint32_t n_views,
@@ -40,7 +43,8 @@ bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, c
 // triangle set-up (micro-triangles resolved, clip list and pending lists filled) followed by the binning of the pending lists
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0,
-                  hipEvent_t between /* recorded between set-up and binning, may be null */, bool bin = true /* false: set-up only */);
+                  hipEvent_t between /* recorded between set-up and binning, may be null */, bool bin = true /* false: set-up only */,
+                  uint32_t fill_blocks = kFillBlocks);
 // near-plane clipping of the triangles set-up listed: cuts them and resolves the pieces into the visibility buffer.
 // Runs after launch_setup and before launch_scan (which reports the counters to the host).
 void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const float* px, const float* py, const float* pz,
