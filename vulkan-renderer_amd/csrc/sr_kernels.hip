@@ -220,8 +220,8 @@ __device__ inline MicroEdges micro_edges(const int2& v0, const int2& v1, const i
     return e;
 }
 // Product of two factors of the edge functions of a triangle whose box is under 64 pixels (each below 2^15, the product
-// below 2^31).  (The 24-bit multiplier, __mul24, would be exact here too; measured, it made the set-up kernel 13 % longer in
-// instructions and no faster, and the 32-bit tile path 16 % slower.)
+// below 2^31).  (The 24-bit multiplier, __mul24, would be exact here too; measured, it made the sample walks longer in
+// instructions and the 32-bit tile path 16 % slower.  The facing test of the set-up kernel, outside any loop, does use it.)
 __device__ inline int32_t mul_small(int32_t a, int32_t b) { return a * b; }
 
 __device__ inline void micro_eval(const MicroEdges& e, int32_t px, int32_t py, int32_t& Ea, int32_t& Eb, int32_t& Ec)
@@ -230,12 +230,14 @@ __device__ inline void micro_eval(const MicroEdges& e, int32_t px, int32_t py, i
     Eb = mul_small(e.ax - e.cx, py - e.cy) - mul_small(e.ay - e.cy, px - e.cx);
     Ec = mul_small(e.bx - e.ax, py - e.ay) - mul_small(e.by - e.ay, px - e.ax);
 }
-// bit ((j*npx + i)*S + s) set when sample s of pixel (x0+i, y0+j) is covered.  Edge functions are
-// stepped incrementally (exact in integers) from their value at the box's first pixel.
+// Draws a micro-triangle: every sample of its box is tested with the edge functions, stepped incrementally (exact in integers) from
+// their value at the box's first pixel, and each covered sample goes into the visibility buffer with a 64-bit atomic min.  Depth is
+// the tile rasteriser's expression of the unbiased edge values.  Returns whether any sample was covered.
 template <int S>
-__device__ inline uint32_t micro_coverage(const MicroEdges& e, int x0, int y0, int npx, int npy)
+__device__ inline bool micro_draw(const MicroEdges& e, int x0, int y0, int npx, int npy, float z0, float z1, float z2, float rA,
+                                  uint32_t tri, unsigned long long* vis_view, const FrameGeom& g)
 {
-    uint32_t cov = 0;
+    bool any = false;
     const int32_t sxa = -(e.cy - e.by) * kSubpix, sya = (e.cx - e.bx) * kSubpix;   // change per pixel step in x / y
     const int32_t sxb = -(e.ay - e.cy) * kSubpix, syb = (e.ax - e.cx) * kSubpix;
     const int32_t sxc = -(e.by - e.ay) * kSubpix, syc = (e.bx - e.ax) * kSubpix;
@@ -244,41 +246,37 @@ __device__ inline uint32_t micro_coverage(const MicroEdges& e, int x0, int y0, i
         int32_t Ra, Rb, Rc;
         micro_eval(e, x0 * kSubpix + sample_dx(S, s), y0 * kSubpix + sample_dy(S, s), Ra, Rb, Rc);
         Ra += e.bias_a; Rb += e.bias_b; Rc += e.bias_c;
-        int bit = s;
+        unsigned long long* row = vis_view + ((size_t)(y0 - g.ry) * g.rw + (x0 - g.rx)) * S + s;
         for (int j = 0; j < npy; ++j) {
             int32_t Ea = Ra, Eb = Rb, Ec = Rc;
             for (int i = 0; i < npx; ++i) {
-                if ((Ea | Eb | Ec) >= 0) cov |= 1u << bit;
+                if ((Ea | Eb | Ec) >= 0) {
+                    any = true;
+                    const float l0 = (float)(Ea - e.bias_a) * rA, l2 = (float)(Eb - e.bias_b) * rA, l1 = (float)(Ec - e.bias_c) * rA;
+                    float z = fmaf(l2, z2, fmaf(l1, z1, l0 * z0));
+                    z = z + 0.0f;
+                    if (z >= 0.0f && z < 1.0f) atomicMin(&row[(size_t)i * S], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
+                }
                 Ea += sxa; Eb += sxb; Ec += sxc;
-                bit += S;
             }
             Ra += sya; Rb += syb; Rc += syc;
+            row += (size_t)g.rw * S;
         }
     }
-    return cov;
+    return any;
 }
+
+// The pixels whose sample points the bounding box of a triangle can hold, clipped to the stored rectangle: false if there are none.
 template <int S>
-__device__ inline void micro_resolve(const MicroEdges& e, uint32_t cov, int x0, int y0, int npx, float z0, float z1, float z2, float rA,
-                                     uint32_t tri, unsigned long long* vis_view, const FrameGeom& g)
+__device__ inline bool sample_box(int mnx, int mxx, int mny, int mxy, const FrameGeom& g, int& x0, int& y0, int& npx, int& npy)
 {
-    // walk the box in the same order as micro_coverage; cov is usually one or two bits
-    int i = 0, j = 0;
-    for (uint32_t m = cov; m; ) {
-        uint32_t here = m & ((1u << S) - 1u);
-        m >>= S;
-        for (; here; here &= here - 1u) {
-            const int s = __ffs((int)here) - 1;
-            const int x = x0 + i, y = y0 + j;
-            int32_t Ea, Eb, Ec;
-            micro_eval(e, x * kSubpix + sample_dx(S, s), y * kSubpix + sample_dy(S, s), Ea, Eb, Ec);
-            const float l0 = (float)Ea * rA, l2 = (float)Eb * rA, l1 = (float)Ec * rA;
-            float z = fmaf(l2, z2, fmaf(l1, z1, l0 * z0));
-            z = z + 0.0f;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri;
-            if (z >= 0.0f && z < 1.0f) atomicMin(&vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S + s], key);
-        }
-        if (++i == npx) { i = 0; ++j; }
-    }
+    int x1, y1;
+    pixel_span<S>(mnx, mxx, x0, x1);
+    pixel_span<S>(mny, mxy, y0, y1);
+    x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+    y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+    npx = x1 - x0 + 1; npy = y1 - y0 + 1;
+    return npx > 0 && npy > 0;
 }
 
 // The hardware deals workgroups to the eight XCDs round robin by linear workgroup id, and every XCD has an L2 of its own.  Neighbouring
@@ -311,7 +309,7 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     __shared__ uint32_t s_wave[kSetupTris * 4];
     __shared__ uint32_t s_micro[4];
     __shared__ uint32_t s_base;
-    __shared__ uint32_t s_q_tri[kSetupBlockTris], s_q_cov[kSetupBlockTris], s_q_box[kSetupBlockTris];
+    __shared__ uint32_t s_q_tri[kSetupBlockTris], s_q_i0[kSetupBlockTris], s_q_i1[kSetupBlockTris], s_q_i2[kSetupBlockTris];
     __shared__ uint32_t s_q_count;
     const uint32_t turn = xcd_runs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const uint32_t blk = turn % gridDim.x, view_begin = turn / gridDim.x * views_per_block;
@@ -331,66 +329,69 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     // 5 % on a one-view frame of 10 M triangles)
     const uint32_t view_end = VIEW_LOOP ? min(view_begin + views_per_block, n_views) : view_begin + 1u;
     for (uint32_t view = view_begin; view < view_end; ++view) {
+    if (tid == 0) s_q_count = 0u;
+    __syncthreads();
     const int2* xy = sp.xy + (size_t)view * sp.stride;
     int2 r0[kSetupTris], r1[kSetupTris], r2[kSetupTris];
 #pragma unroll
     for (uint32_t k = 0; k < kSetupTris; ++k) { r0[k] = xy[i0[k]]; r1[k] = xy[i1[k]]; r2[k] = xy[i2[k]]; }
 
+    // Phase one: the cheap tests, for every triangle.  Micro-triangles whose box holds a sample point are queued in LDS (their id and
+    // their three indices); phase two takes them one per work-item, every lane busy, fetches positions and depths (cache hits: the
+    // workgroup touched those lines a moment ago), walks the few samples and does the atomic mins.  Run in place, at the one lane in
+    // three or ten that holds such a triangle, the sample walk was most of the kernel's instructions.
     uint32_t n_unproj = 0, n_micro = 0;
-    uint32_t micro_cov[kSetupTris], micro_box[kSetupTris];   // coverage bits; x0 | y0<<14 | (npx-1)<<28
-    bool pend[kSetupTris];
+    bool pend[kSetupTris], queued[kSetupTris];
 #pragma unroll
     for (uint32_t k = 0; k < kSetupTris; ++k) {
-        micro_cov[k] = 0; micro_box[k] = 0; pend[k] = false;
-        const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
+        pend[k] = false; queued[k] = false;
         const int mnx = min(r0[k].x, min(r1[k].x, r2[k].x)), mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
         const int mny = min(r0[k].y, min(r1[k].y, r2[k].y)), mxy = max(r0[k].y, max(r1[k].y, r2[k].y));
         // facing: the sign of the doubled area.  A box under 64 pixels on both axes (differences in unsigned arithmetic: x is INT32_MIN
-        // for a vertex that cannot be projected) keeps every factor below 2^15: the 24-bit multiplier is exact; else 64 bits.
+        // for a vertex that cannot be projected) keeps every factor below 2^15: the 24-bit multiplier is exact and the products fit 32
+        // bits; else 64 bits -- a path the wave skips unless one of its triangles needs it.
         const bool small_box = (uint32_t)mxx - (uint32_t)mnx < 16384u && (uint32_t)mxy - (uint32_t)mny < 16384u;
-        bool front;
-        if (small_box) front = mul_small(r1[k].x - r0[k].x, r2[k].y - r0[k].y) - mul_small(r2[k].x - r0[k].x, r1[k].y - r0[k].y) < 0;
-        else front = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
-                     (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y) < 0;
-        if (in_range[k] && bad > 0 && bad < 3) {
-            // needs the near-plane clipper; a full list drops and counts the triangle
-            const uint32_t slot = atomicAdd(&b.counters[kCtrClipListed], 1u);
-            if (slot < clip.capacity) clip.entries[slot] = make_uint2(view, tri[k]);
-            else ++n_unproj;
+        // (differences in unsigned arithmetic, which wraps: for a larger box the 32-bit value means nothing and is replaced below)
+        bool front = __mul24((int)((uint32_t)r1[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r2[k].y - (uint32_t)r0[k].y)) -
+                     __mul24((int)((uint32_t)r2[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r1[k].y - (uint32_t)r0[k].y)) < 0;
+        if (__ballot(!small_box) != 0ull) {
+            if (!small_box) front = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
+                                    (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y) < 0;
         }
-        if (in_range[k] && bad == 0 && front) {
-            int x0, x1, y0, y1;
-            pixel_span<S>(mnx, mxx, x0, x1);
-            pixel_span<S>(mny, mxy, y0, y1);
-            x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
-            y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
-            const int npx = x1 - x0 + 1, npy = y1 - y0 + 1;
-            if (npx > 0 && npy > 0) {
-                if (npx * npy <= micro_pixels<S>() && small_box) {
-                    micro_cov[k] = micro_coverage<S>(micro_edges(r0[k], r1[k], r2[k]), x0, y0, npx, npy);
-                    micro_box[k] = (uint32_t)x0 | ((uint32_t)y0 << 14) | ((uint32_t)(npx - 1) << 28);
-                    if (micro_cov[k]) ++n_micro;
-                } else pend[k] = true;
+        // a vertex that cannot be projected has x = INT32_MIN, which then is the smallest x of the triangle
+        const bool any_bad = mnx == kBadVertexX;
+        if (__ballot(any_bad && in_range[k]) != 0ull) {   // rare
+            const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
+            if (in_range[k] && bad > 0 && bad < 3) {
+                // needs the near-plane clipper; a full list drops and counts the triangle
+                const uint32_t slot = atomicAdd(&b.counters[kCtrClipListed], 1u);
+                if (slot < clip.capacity) clip.entries[slot] = make_uint2(view, tri[k]);
+                else ++n_unproj;
+            }
+        }
+        if (in_range[k] && !any_bad && front) {
+            int x0, y0, npx, npy;
+            if (sample_box<S>(mnx, mxx, mny, mxy, g, x0, y0, npx, npy)) {
+                if (__mul24(npx, npy) <= micro_pixels<S>() && small_box) queued[k] = true;   // (npx, npy <= 16384)
+                else pend[k] = true;
             }
         }
     }
-    // Micro-triangles with a covered sample are queued in LDS and resolved in a second, dense phase: a work-item per
-    // queued triangle fetches its indices, positions and depths again (cache hits: the workgroup touched those lines a
-    // moment ago) and does the atomic mins.  The first phase then carries neither depths nor the resolve code in its
-    // registers, and the second runs with every lane busy instead of the one lane in two or three that holds a covered
-    // triangle.
-    if (tid == 0) s_q_count = 0u;
-    __syncthreads();
+    {   // the wave's queued triangles take their places in the workgroup's queue: one LDS atomic per wave
+        uint64_t qm[kSetupTris];
+        uint32_t n = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kSetupTris; ++k) {
-        const bool queued = micro_cov[k] != 0u;
-        const uint64_t mask = __ballot(queued);
+        for (uint32_t k = 0; k < kSetupTris; ++k) { qm[k] = __ballot(queued[k]); n += (uint32_t)__popcll(qm[k]); }
         uint32_t base = 0;
-        if (lane == 0 && mask) base = atomicAdd(&s_q_count, (uint32_t)__popcll(mask));
+        if (lane == 0 && n) base = atomicAdd(&s_q_count, n);
         base = (uint32_t)__shfl((int)base, 0);
-        if (queued) {
-            const uint32_t q = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            s_q_tri[q] = tri[k]; s_q_cov[q] = micro_cov[k]; s_q_box[q] = micro_box[k];
+#pragma unroll
+        for (uint32_t k = 0; k < kSetupTris; ++k) {
+            if (queued[k]) {
+                const uint32_t q = base + (uint32_t)__popcll(qm[k] & ((1ull << lane) - 1ull));
+                s_q_tri[q] = tri[k]; s_q_i0[q] = i0[k]; s_q_i1[q] = i1[k]; s_q_i2[q] = i2[k];
+            }
+            base += (uint32_t)__popcll(qm[k]);
         }
     }
     __syncthreads();
@@ -399,13 +400,13 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
         unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
         const uint32_t n_q = s_q_count;
         for (uint32_t q = tid; q < n_q; q += 256u) {
-            const uint32_t t = s_q_tri[q], cov = s_q_cov[q], box = s_q_box[q];
-            const uint32_t j0 = idx[3 * (size_t)t], j1 = idx[3 * (size_t)t + 1], j2 = idx[3 * (size_t)t + 2];
+            const uint32_t t = s_q_tri[q], j0 = s_q_i0[q], j1 = s_q_i1[q], j2 = s_q_i2[q];
             const int2 a0 = xy[j0], a1 = xy[j1], a2 = xy[j2];
             const float za = zp[j0], zb = zp[j1], zc = zp[j2];
-            const int bx0 = (int)(box & 16383u), by0 = (int)((box >> 14) & 16383u), bnpx = (int)(box >> 28) + 1;
+            int x0, y0, npx, npy;
+            sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
             const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
-            micro_resolve<S>(micro_edges(a0, a1, a2), cov, bx0, by0, bnpx, za, zb, zc, 1.0f / (float)A, t, vis_view, g);
+            if (micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_view, g)) ++n_micro;
         }
     }
     if (n_unproj) atomicAdd(&b.counters[kCtrUnprojectable], n_unproj);   // rare
