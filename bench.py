@@ -55,10 +55,23 @@ def kernel_bytes(st, n_tiles):
     B, R, Fd, F, Pv = st["triangles_binned"], st["tile_refs"], st["triangles_direct"], st["visible_triangles"], st["shaded_pixels"]
     X = Pv * 3 * 1.33                       # unique texels over the three maps (model)
     direct_samples = Pv * S * (Fd / max(F, 1)) if F else 0
+    # V and T are summed over the views; a pass reads positions (vertex kernel) and, when its workgroups take every view of the pass
+    # (a mesh large enough to fill the chip that way), indices (set-up kernel) once for all its views
+    views, passes = max(st.get("views", 1), 1), max(st.get("passes", 1), 1)
+    per_pass = -(-views // passes)
+
+    def reads_per_view(units_per_view, block_units, fused=False):
+        """How often, per view, a kernel whose workgroups take several views of a pass reads the mesh (the launchers' rule: all views
+        of the pass per workgroup unless that leaves fewer than 4096 workgroups)."""
+        grid_x = -(-units_per_view // block_units)
+        per_block = per_pass if fused else min(max(per_pass * grid_x // 4096, 1), per_pass)
+        return passes * -(-per_pass // per_block) / views
+    vertex_reads = reads_per_view(V // views, 512, fused=views <= 8)
+    index_reads = reads_per_view(T // views, 768)
     return {
-        "clear": P * S * 8,                                                   # visibility words written
-        "vertex": V * 12 + V * 16,                                             # positions read, xy + (z, 1/w) planes written
-        "setup": T * 12 + V * 8 + min(V, 3 * Fd) * 8 + direct_samples * 8 + B * 4,   # indices, xy plane, z of covered micro-triangles, atomic-min words, pending ids
+        "clear": P * S * 8,                                                   # visibility words written (only the covered blocks are; counted in full)
+        "vertex": V * 12 * vertex_reads + V * 12,                              # positions read, xy + z planes written
+        "setup": T * 12 * index_reads + V * 8 + min(V, 3 * Fd) * 4 + direct_samples * 8 + B * 4,   # indices, xy plane, z of covered micro-triangles, atomic-min words, pending ids
         "bin": B * 4 + B * 12 + min(V, 3 * B) * 8 + R * 12,                   # pending ids, indices, xy, records
         "scan": n_tiles * 12,
         "fill": R * 12 + R * 4,                                                # records read, references written
@@ -291,6 +304,7 @@ def main():
         sr.draw(dev, tgt, mesh, ubo, tex)
     stats = tgt.stats()
     stats["samples"] = samples
+    stats["views"] = views
     elapsed = own_elapsed = timed(tex, args.steps)
     if world > 1:
         torch.cuda.synchronize()
@@ -352,6 +366,8 @@ def main():
             "kernel_algorithmic_MB": {k: round(v / 1e6, 1) for k, v in by.items()},
             "frame_algorithmic_bytes": int(frame_bytes),
             "frame_hbm_fraction": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            **({"frame_hbm_fraction_note": "the frame figure counts every view's mesh reads; a batch reads positions and indices once per pass of "
+                                             f"{-(-views // max(stats.get('passes', 1), 1))} views, so this is not a fraction of what the kernels had to move"} if views > 1 else {}),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(workload, dom), "algorithmic_bytes": int(by[dom]),
                          "kernel_source_digest": kernel_source_digest()},

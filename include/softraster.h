@@ -77,6 +77,8 @@ typedef struct sr_draw_stats {
     uint64_t triangles_clipped;   /* triangles with a vertex behind the eye (or outside the guard band) that were cut at the near
                                      plane and drawn: the fixed-function clipping of the reference's pipeline
                                      (depthClampEnable = VK_FALSE, src/main.cpp:586) */
+    uint64_t passes;              /* passes the draw ran as: the views of a batch are drawn as many at a time as the per-view scratch
+                                     buffers fit the budget; positions and indices are read once per pass, not once per view */
 } sr_draw_stats;
 
 /* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */

@@ -885,6 +885,7 @@ int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)
     out->triangles_binned = target->binned;
     out->triangles_direct = target->micro;
     out->triangles_clipped = target->clipped;
+    out->passes = target->passes;
     return SR_OK;
 }
 

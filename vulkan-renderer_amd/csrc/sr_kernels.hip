@@ -991,8 +991,13 @@ struct Taps {
     uint32_t o00, o10, o01, o11;
     float w00, w10, w01, w11;
 };
+// SR_COLOUR_MATH: the functions of the shading pass that feed nothing but the colour (allowed 1 LSB of the 8-bit result against the
+// CPU oracle) let the compiler fuse multiplies and adds; everything that feeds coverage, depth or triangle ids is compiled unfused
+// (-ffp-contract=off), like the oracle.
+#define SR_COLOUR_MATH _Pragma("clang fp contract(fast)")
 __device__ inline Taps level_taps(int w, int h, const uint32_t* lvl /* level offsets, LDS */, int level, float s, float tt)
 {
+    SR_COLOUR_MATH
     const int wl = max(w >> level, 1), hl = max(h >> level, 1);
     const uint32_t base = lvl[level];   // (an LDS copy: a per-lane index into kernel arguments would be a memory load)
     const float u = s * (float)wl - 0.5f, v = tt * (float)hl - 0.5f;
@@ -1024,6 +1029,7 @@ __device__ inline uint32_t texel_at(const uint32_t* texels, uint32_t index)
 template <int NCH>
 __device__ inline void fetch_taps(const uint32_t* texels, const Taps& t, const float* dec, float* o)
 {
+    SR_COLOUR_MATH
     const uint32_t c00 = texel_at(texels, t.o00), c10 = texel_at(texels, t.o10), c01 = texel_at(texels, t.o01), c11 = texel_at(texels, t.o11);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -1047,6 +1053,7 @@ struct TrilinearTaps {
 // texture() with the 2x2-quad differences supplied; isotropic LOD, trilinear, REPEAT
 __device__ inline TrilinearTaps trilinear_taps(const TexDesc& t, const uint32_t* lvl, float s, float tt, float dsdx, float dtdx, float dsdy, float dtdy)
 {
+    SR_COLOUR_MATH
     const float mux = dsdx * (float)t.w, mvx = dtdx * (float)t.h;
     const float muy = dsdy * (float)t.w, mvy = dtdy * (float)t.h;
     const float rx2 = mux * mux + mvx * mvx, ry2 = muy * muy + mvy * mvy;
@@ -1068,6 +1075,7 @@ __device__ inline TrilinearTaps trilinear_taps(const TexDesc& t, const uint32_t*
 template <int NCH>
 __device__ inline void fetch_trilinear(const uint32_t* texels, const TrilinearTaps& tp, const float* dec, float* o)
 {
+    SR_COLOUR_MATH
     float chi[NCH];
     fetch_taps<NCH>(texels, tp.hi, dec, chi);
     if (tp.delta == 0.0f) {
@@ -1095,6 +1103,7 @@ template <int NCH>
 __device__ inline void sample_texture_aniso(const TexDesc& t, const uint32_t* lvl, float s, float tt, float dsdx, float dtdx,
                                             float dsdy, float dtdy, const float* dec, float* o)
 {
+    SR_COLOUR_MATH
     const float max_aniso = t.max_aniso;
     if (!(max_aniso > 1.0f)) { sample_texture<NCH>(t, lvl, s, tt, dsdx, dtdx, dsdy, dtdy, dec, o); return; }   // uniform over the launch
     const float mux = dsdx * (float)t.w, mvx = dtdx * (float)t.h;
@@ -1163,6 +1172,7 @@ __device__ inline float geometry_schlick_ggx(float NdotV, float roughness)
 __device__ inline void fragment_main(const float* wp, const float* N, const float* cam, const float* albedo_tex,
                                      float metallic, float roughness, float* out)
 {
+    SR_COLOUR_MATH
     const float kPI = 3.14159265359f, kInvPI = 1.0f / 3.14159265359f;
     const float albedo[3] = { fast_pow(albedo_tex[0], 2.2f), fast_pow(albedo_tex[1], 2.2f), fast_pow(albedo_tex[2], 2.2f) };
     const float ao = 0.01f;
@@ -1281,6 +1291,9 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
         mat3_mul_vec3(vx.model, a1.w, b1.x, b1.y, n1);
         mat3_mul_vec3(vx.model, a2.w, b2.x, b2.y, n2);
     }
+    // (from here on nothing but the colour depends on the arithmetic)
+    {
+    SR_COLOUR_MATH
     float q0, q1, q2, q0x, q1x, q2x, q0y, q1y, q2y;
     if (v0.rw != 0.0f && v1.rw != 0.0f && v2.rw != 0.0f) {
         const int32_t px = x * kSubpix + kHalf, py = y * kSubpix + kHalf;
@@ -1348,6 +1361,7 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     const uint32_t G = (uint32_t)srgb_encode8(rgb[1] > 1.0f ? 1.0f : rgb[1], thr);
     const uint32_t B = (uint32_t)srgb_encode8(rgb[2] > 1.0f ? 1.0f : rgb[2], thr);
     return B | (G << 8) | (R << 16) | (255u << 24);
+    }
 }
 
 // One work-item per pixel, workgroups of kFragBlockW x kFragBlockH pixels.  The launch shape and the

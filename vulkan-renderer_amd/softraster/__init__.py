@@ -51,7 +51,7 @@ class Rect(C.Structure):
 
 class DrawStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("vertices", "triangles", "triangles_binned", "tile_refs", "triangles_unprojectable",
-                                           "shaded_pixels", "visible_triangles", "pixels", "triangles_direct", "triangles_clipped")]
+                                           "shaded_pixels", "visible_triangles", "pixels", "triangles_direct", "triangles_clipped", "passes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
