@@ -150,6 +150,12 @@ TexDesc make_tex_desc(const sr_texture_t* t)
 {
     TexDesc d{};
     d.texels = t->d_chain; d.w = t->w; d.h = t->h; d.levels = t->levels;
+    d.log2_w = d.log2_h = -1;
+    if ((t->w & (t->w - 1)) == 0 && (t->h & (t->h - 1)) == 0) {
+        d.log2_w = d.log2_h = 0;
+        while ((1 << d.log2_w) < t->w) ++d.log2_w;
+        while ((1 << d.log2_h) < t->h) ++d.log2_h;
+    }
     d.min_lod = t->samp.min_lod;
     d.max_lod = t->samp.max_lod < 0.0f ? (float)t->levels : t->samp.max_lod;
     d.bias = t->samp.mip_lod_bias;

@@ -57,6 +57,7 @@ struct ScreenPlanes {
 struct TexDesc {
     const uint32_t* texels;  // RGBA8, all levels back to back
     int w, h, levels;
+    int log2_w, log2_h;      // both sizes powers of two: their logarithms (every level then is one too: wrap with a mask, rows by a shift); else -1
     float min_lod, max_lod, bias;
     float max_aniso;         // the sampler's maxAnisotropy (src/texture.cpp:255-256); <= 1: isotropic footprint
     uint32_t level_off[kMaxMipLevels];  // in texels

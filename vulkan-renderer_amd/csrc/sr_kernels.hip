@@ -995,27 +995,29 @@ struct Taps {
 // CPU oracle) let the compiler fuse multiplies and adds; everything that feeds coverage, depth or triangle ids is compiled unfused
 // (-ffp-contract=off), like the oracle.
 #define SR_COLOUR_MATH _Pragma("clang fp contract(fast)")
-__device__ inline Taps level_taps(int w, int h, const uint32_t* lvl /* level offsets, LDS */, int level, float s, float tt)
+__device__ inline Taps level_taps(const TexDesc& tex, const uint32_t* lvl /* level offsets, LDS */, int level, float s, float tt)
 {
     SR_COLOUR_MATH
-    const int wl = max(w >> level, 1), hl = max(h >> level, 1);
     const uint32_t base = lvl[level];   // (an LDS copy: a per-lane index into kernel arguments would be a memory load)
+    const bool pow2 = tex.log2_w >= 0;   // the same for the whole launch
+    const int sw = max(tex.log2_w - level, 0);
+    const int wl = pow2 ? 1 << sw : max(tex.w >> level, 1), hl = pow2 ? 1 << max(tex.log2_h - level, 0) : max(tex.h >> level, 1);
     const float u = s * (float)wl - 0.5f, v = tt * (float)hl - 0.5f;
-    float fu = floorf(u), fv = floorf(v);
-    const float a = u - fu, b = v - fv;
     const float lim = 1073741824.0f;
-    if (!(fu > -lim)) fu = -lim; if (fu > lim) fu = lim;
-    if (!(fv > -lim)) fv = -lim; if (fv > lim) fv = lim;
+    const float fu = fminf(fmaxf(floorf(u), -lim), lim), fv = fminf(fmaxf(floorf(v), -lim), lim);   // (a NaN becomes -lim)
+    const float a = u - floorf(u), b = v - floorf(v);
     int i0, j0, i1, j1;
-    if (((wl & (wl - 1)) | (hl & (hl - 1))) == 0) {   // power-of-two level: wrap with a mask
+    uint32_t r0, r1;   // a chain holds fewer than 2^30 texels (16384^2 * 4/3)
+    if (pow2) {   // wrap with a mask, rows by a shift
         i0 = (int)fu & (wl - 1); j0 = (int)fv & (hl - 1);
         i1 = (i0 + 1) & (wl - 1); j1 = (j0 + 1) & (hl - 1);
+        r0 = base + ((uint32_t)j0 << sw); r1 = base + ((uint32_t)j1 << sw);
     } else {
         i0 = wrap_repeat((int)fu, wl); j0 = wrap_repeat((int)fv, hl);
         i1 = wrap_repeat(i0 + 1, wl); j1 = wrap_repeat(j0 + 1, hl);
+        r0 = base + (uint32_t)j0 * (uint32_t)wl; r1 = base + (uint32_t)j1 * (uint32_t)wl;
     }
     Taps t;
-    const uint32_t r0 = base + (uint32_t)j0 * (uint32_t)wl, r1 = base + (uint32_t)j1 * (uint32_t)wl;   // a chain holds fewer than 2^30 texels (16384^2 * 4/3)
     t.o00 = r0 + (uint32_t)i0; t.o10 = r0 + (uint32_t)i1; t.o01 = r1 + (uint32_t)i0; t.o11 = r1 + (uint32_t)i1;
     t.w00 = (1.0f - a) * (1.0f - b); t.w10 = a * (1.0f - b); t.w01 = (1.0f - a) * b; t.w11 = a * b;
     return t;
@@ -1042,7 +1044,7 @@ __device__ inline void fetch_taps(const uint32_t* texels, const Taps& t, const f
 template <int NCH>
 __device__ inline void sample_level(const TexDesc& t, const uint32_t* lvl, int level, float s, float tt, const float* dec, float* o)
 {
-    fetch_taps<NCH>(t.texels, level_taps(t.w, t.h, lvl, level, s, tt), dec, o);
+    fetch_taps<NCH>(t.texels, level_taps(t, lvl, level, s, tt), dec, o);
 }
 
 // The two footprints of a trilinear fetch and the weight of the coarser one (0: the finer level alone).
@@ -1067,9 +1069,9 @@ __device__ inline TrilinearTaps trilinear_taps(const TexDesc& t, const uint32_t*
     const int lhi = (int)dhi, llo = min(lhi + 1, t.levels - 1);
     TrilinearTaps tp;
     tp.delta = d - dhi;
-    tp.hi = level_taps(t.w, t.h, lvl, lhi, s, tt);
+    tp.hi = level_taps(t, lvl, lhi, s, tt);
     tp.lo = tp.hi;
-    if (tp.delta != 0.0f) tp.lo = level_taps(t.w, t.h, lvl, llo, s, tt);
+    if (tp.delta != 0.0f) tp.lo = level_taps(t, lvl, llo, s, tt);
     return tp;
 }
 template <int NCH>
