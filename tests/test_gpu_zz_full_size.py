@@ -94,7 +94,7 @@ def test_second_draw_gives_the_same_frame(sr, device, frame):
     assert np.array_equal(tgt.read_triangle_ids(0)[..., 0], frame["tri"])
     assert np.array_equal(tgt.read_depth(0)[..., 0].view(np.uint32), frame["depth"].view(np.uint32))
     assert np.array_equal(tgt.read_color(0), frame["bgra"])
-    # (tile_refs may drop to 0: with the sparse-tail variant a repeated frame skips the tile lists)
+    # (tile_refs may drop to 0: a repeated frame that left nothing pending is drawn lean, without the tile lists)
     again = tgt.stats()
     assert {k: v for k, v in again.items() if k != "tile_refs"} == {k: v for k, v in frame["stats"].items() if k != "tile_refs"}
     assert again["tile_refs"] in (0, frame["stats"]["tile_refs"])

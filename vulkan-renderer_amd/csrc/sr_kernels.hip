@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
         // bits; else 64 bits -- a path the wave skips unless one of its triangles needs it.
         const bool small_box = (uint32_t)mxx - (uint32_t)mnx < 16384u && (uint32_t)mxy - (uint32_t)mny < 16384u;
         // (differences in unsigned arithmetic, which wraps: for a larger box the 32-bit value means nothing and is replaced below)
-        bool front = __mul24((int)((uint32_t)r1[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r2[k].y - (uint32_t)r0[k].y)) -
-                     __mul24((int)((uint32_t)r2[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r1[k].y - (uint32_t)r0[k].y)) < 0;
+        bool front = (int32_t)((uint32_t)__mul24((int)((uint32_t)r1[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r2[k].y - (uint32_t)r0[k].y)) -
+                               (uint32_t)__mul24((int)((uint32_t)r2[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r1[k].y - (uint32_t)r0[k].y))) < 0;
         if (__ballot(!small_box) != 0ull) {
             if (!small_box) front = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
                                     (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y) < 0;
