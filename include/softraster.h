@@ -197,6 +197,13 @@ SR_API int sr_draw_no_alloc(sr_device dev, sr_target target, sr_mesh mesh, const
                             uint32_t n_views, size_t ubo_stride, const sr_texture textures[4]);
 SR_API size_t sr_no_alloc_scratch_bytes(void);
 
+/* ---- normal mapping: getNormalFromMap of shaders/shader.frag:35-53 with the body the reference has commented out restored
+ * (tangent frame from the screen-space derivatives of WorldPos and TexCoord, tangent-space normal from textures[1] through the
+ * same sampler and sRGB image format as every other map, src/texture.cpp:209).  Off by default: the reference returns the
+ * interpolated normal, and so does this library unless asked.  enabled != 0 makes every draw issued on the device afterwards
+ * shade with the mapped normal (textures[1] is then required). */
+SR_API int sr_device_set_normal_mapping(sr_device dev, int enabled);
+
 /* ---- instrumentation (no reference counterpart) */
 SR_API int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out);
 /* When enabled, sr_draw brackets every stage with HIP events on the device's stream. */

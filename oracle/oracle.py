@@ -74,6 +74,12 @@ def set_anisotropic(on: bool):
     lib().sro_set_anisotropic(1 if on else 0)
 
 
+def set_normal_mapping(on: bool):
+    """Switches the normal map on or off for every later draw (off by default: shaders/shader.frag:35-53 returns the interpolated
+    normal, the body that reads the map is commented out in the reference)."""
+    lib().sro_set_normal_mapping(1 if on else 0)
+
+
 def srgb_tables():
     dec = np.empty(256, np.float32)
     thr = np.empty(255, np.float32)

@@ -727,6 +727,10 @@ static float interp(float p0, float p1, float p2, float a0, float a1, float a2)
     return fmaf(p2, a2, fmaf(p1, a1, p0 * a0));
 }
 
+/* getNormalFromMap of shaders/shader.frag:35-53 with its body (commented out in the reference) restored; off by default */
+static int g_normal_mapping = 0;
+SRO_API void sro_set_normal_mapping(int on) { g_normal_mapping = on; }
+
 /* shade triangle ti at pixel (x,y): returns packed B,G,R,A bytes */
 static uint32_t shade_pixel(const shade_ctx* c, uint32_t ti, int x, int y)
 {
@@ -746,7 +750,7 @@ static uint32_t shade_pixel(const shade_ctx* c, uint32_t ti, int x, int y)
     float u = interp(p0, p1, p2, a0[6], a1[6], a2[6]), v = interp(p0, p1, p2, a0[7], a1[7], a2[7]);
     /* coarse derivatives over the 2x2 quad, evaluated for this triangle (helper invocations) */
     int qx = x & ~1, qy = y & ~1;
-    float uq[3], vq[3];
+    float uq[3], vq[3], wq[3][3];
     const int off[3][2] = { {0, 0}, {1, 0}, {0, 1} };
     for (int k = 0; k < 3; ++k) {
         float r0, r1, r2;
@@ -754,8 +758,24 @@ static uint32_t shade_pixel(const shade_ctx* c, uint32_t ti, int x, int y)
         else persp_weights(&t, (int64_t)(qx + off[k][0]) * SUBPIX + HALF, (int64_t)(qy + off[k][1]) * SUBPIX + HALF, &r0, &r1, &r2);
         uq[k] = interp(r0, r1, r2, a0[6], a1[6], a2[6]);
         vq[k] = interp(r0, r1, r2, a0[7], a1[7], a2[7]);
+        for (int j = 0; j < 3; ++j) wq[k][j] = interp(r0, r1, r2, w0[j], w1[j], w2[j]);
     }
     float dudx = uq[1] - uq[0], dvdx = vq[1] - vq[0], dudy = uq[2] - uq[0], dvdy = vq[2] - vq[0];
+    if (g_normal_mapping) {
+        float tn[4], Q1[3], Q2[3], Nn[3], T[3], B[3], M[3];
+        sample_texture(&c->tex[1], u, v, dudx, dvdx, dudy, dvdy, tn, NULL);       /* texture(normalMapSampler, TexCoord).xyz * 2.0 - 1.0 */
+        for (int j = 0; j < 3; ++j) {
+            tn[j] = tn[j] * 2.0f - 1.0f;
+            Q1[j] = wq[1][j] - wq[0][j]; Q2[j] = wq[2][j] - wq[0][j];             /* dFdx(WorldPos), dFdy(WorldPos) */
+            T[j] = Q1[j] * dvdy - Q2[j] * dvdx;                                   /* Q1*st2.t - Q2*st1.t */
+        }
+        glsl_normalize(N, Nn);
+        glsl_normalize(T, T);
+        v3_cross(Nn, T, B);
+        glsl_normalize(B, B);                                                     /* B = -normalize(cross(N, T)) */
+        for (int j = 0; j < 3; ++j) M[j] = (T[j] * tn[0] - B[j] * tn[1]) + Nn[j] * tn[2];   /* mat3(T, B, N) * tangentNormal */
+        glsl_normalize(M, N);
+    }
     float alb[4], met[4], rgh[4], rgb[3];
     sample_texture(&c->tex[0], u, v, dudx, dvdx, dudy, dvdy, alb, NULL);
     sample_texture(&c->tex[2], u, v, dudx, dvdx, dudy, dvdy, met, NULL);

@@ -473,6 +473,46 @@ def test_view_batch_split_into_passes(sr, oracle, device, samples):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
+def test_normal_mapping(sr, oracle, device, samples, anisotropic):
+    """The normal map read (shaders/shader.frag:35-53 with the body the reference has commented out restored), an option that
+    is off by default: same visibility, colour to the bar against the oracle with the same switch; switched off again the frame
+    is the default one.  A second view with a general model matrix and a lean-eligible repeat of the draw are in the batch."""
+    verts, idx = sr.scene.uv_sphere(64, 48)
+    W, H = 400, 300
+    rng = np.random.default_rng(5)
+    ubos = np.stack([sr.scene.default_camera_ubo(W, H), _random_view(rng, W, H, sr)])
+    images = sr.scene.material_textures(64, seed=3)
+    images[1] = sr.scene.noise_rgba(64, 64, 9)
+    plain = util.gpu_render(sr, device, verts, idx, images, ubos, W, H, samples)
+    mesh = sr.create_mesh_from_data(device, verts, idx)
+    tex = [sr.create_texture(device, im) for im in images]
+    tgt = sr.RenderTarget(device, W, H, samples=samples, n_views=2)
+    device.set_normal_mapping(True)
+    oracle.set_normal_mapping(True)
+    try:
+        for _ in range(2):   # (the second draw of the target would be a lean one if normal mapping allowed it)
+            sr.draw(device, tgt, mesh, ubos, tex)
+            for k in range(2):
+                got = {"tri": tgt.read_triangle_ids(k), "depth": tgt.read_depth(k), "bgra": tgt.read_color(k)}
+                _check_view(got, oracle.draw(ubos[k], verts, idx, images, W, H, samples))
+                covered = (got["tri"] != sr.NO_TRIANGLE).any(axis=-1)
+                changed = np.abs(got["bgra"].astype(int) - plain[k]["bgra"].astype(int)).max(axis=-1) > 4
+                assert changed[covered].mean() > 0.25, f"the normal map changes {changed[covered].mean():.3f} of the covered pixels"
+        with pytest.raises(sr.SoftRasterError):
+            sr.draw(device, tgt, mesh, ubos, [tex[0], None, tex[2], tex[3]])
+        device.set_normal_mapping(False)
+        sr.draw(device, tgt, mesh, ubos, tex)   # switched off again: the default frame
+        for k in range(2):
+            assert np.array_equal(tgt.read_visibility(k), plain[k]["vis"]) and np.array_equal(tgt.read_color(k), plain[k]["bgra"])
+    finally:
+        device.set_normal_mapping(False)
+        oracle.set_normal_mapping(False)
+        tgt.destroy(); mesh.destroy()
+        for t in tex:
+            t.destroy()
+
+
+@pytest.mark.parametrize("samples", [1, 4])
 def test_workgroups_that_take_every_view_of_a_pass(sr, oracle, device, samples):
     """A large mesh drawn for a batch of views: the vertex and set-up kernels load positions and indices once and go
     through the views of the pass one after the other.  SR_FILL_BLOCKS=1 makes them do so for a small mesh too (by

@@ -193,3 +193,54 @@ def test_anisotropic_footprint_is_the_specification_s(oracle):
         assert np.array_equal(iso_like, iso)
     finally:
         oracle.set_anisotropic(False)
+
+
+def test_normal_map_tangent_frame(oracle):
+    """Normal mapping (shaders/shader.frag:35-53 with the commented-out body restored; off by default): a quad in the plane
+    z = 0 under a constant normal map.  The expected normal is rebuilt in float64 from ray casts through the pixel centres of
+    the 2x2 quad (dFdx / dFdy of WorldPos and TexCoord), the tangent frame T, B, N of the shader and the decoded texel; the
+    frame's colour must be the shader's for that normal.  With the switch off the same frame is shaded with the vertex normal."""
+    W, H = 64, 48
+    half = 1.5
+    v, i = scene.screen_quad(z=0.0, half=half, uv_scale=1.0)
+    alb, met, rgh, nrm = (200, 120, 40, 255), 64, 180, (230, 90, 200, 255)
+    tex = [scene.constant_rgba(8, 8, alb), scene.constant_rgba(8, 8, nrm),
+           scene.constant_rgba(4, 4, (met,) * 3 + (255,)), scene.constant_rgba(16, 16, (rgh,) * 3 + (255,))]
+    ubo = scene.default_camera_ubo(W, H)
+    plain = oracle.draw(ubo, v, i, tex, W, H)
+    oracle.set_normal_mapping(True)
+    try:
+        mapped = oracle.draw(ubo, v, i, tex, W, H)
+    finally:
+        oracle.set_normal_mapping(False)
+    assert np.array_equal(plain["tri"], mapped["tri"]) and np.array_equal(plain["depth"], mapped["depth"])
+    dec, _ = oracle.srgb_tables()
+    view = ubo[16:32].reshape(4, 4).T.astype(np.float64); proj = ubo[32:48].reshape(4, 4).T.astype(np.float64)
+    eye = np.array([2.0, 2.0, 2.0])
+
+    def hit(px, py):   # pixel centre -> ray -> plane z = 0
+        ndc = np.array([2 * (px + 0.5) / W - 1, 1 - 2 * (py + 0.5) / H])
+        d = view[:3, :3].T @ np.array([ndc[0] / proj[0, 0], ndc[1] / proj[1, 1], -1.0])
+        return eye + (-eye[2] / d[2]) * d
+
+    uv = lambda p: (p[:2] + half) / (2 * half)
+    tn = np.array([dec[c] for c in nrm[:3]], np.float64) * 2 - 1
+    checked = 0
+    for (x, y) in [(W // 2, H // 2), (W // 2 - 5, H // 2 + 4), (W // 2 + 7, H // 2 - 3), (W // 2 + 2, H // 2 + 7)]:
+        if mapped["tri"][y, x, 0] == 0xFFFFFFFF:
+            continue
+        qx, qy = x & ~1, y & ~1
+        p00, p10, p01 = hit(qx, qy), hit(qx + 1, qy), hit(qx, qy + 1)
+        Q1, Q2, st1, st2 = p10 - p00, p01 - p00, uv(p10) - uv(p00), uv(p01) - uv(p00)
+        N = np.array([0.0, 0.0, 1.0])
+        T = Q1 * st2[1] - Q2 * st1[1]; T /= np.linalg.norm(T)
+        B = np.cross(N, T); B = -B / np.linalg.norm(B)
+        M = T * tn[0] + B * tn[1] + N * tn[2]; M /= np.linalg.norm(M)
+        for frame, normal in ((mapped, M), (plain, N)):
+            want = shader_reference(hit(x, y), normal, eye, [dec[c] for c in alb[:3]], dec[met], dec[rgh])
+            got = frame["bgra"][y, x, [2, 1, 0]].astype(int)
+            for c in range(3):
+                assert abs(int(got[c]) - oracle.srgb_encode8(min(want[c], 1.0))) <= 1, (x, y, c, got, want)
+        checked += 1
+    assert checked >= 3
+    assert (np.abs(mapped["bgra"].astype(int) - plain["bgra"].astype(int)).max(axis=-1) > 8).mean() > 0.2   # the map does change the frame

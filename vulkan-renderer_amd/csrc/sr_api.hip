@@ -74,6 +74,7 @@ struct sr_device_t {
     DeviceBuffer clip;           // entries of the near-plane clip list: capacity x 8 bytes
     uint32_t clip_capacity = 65536;   // triangles per pass that can be clipped; more are dropped and counted
     uint32_t fill_blocks = kFillBlocks;   // see sr_launch.h
+    bool normal_mapping = false;          // sr_device_set_normal_mapping: applies to the draws issued after it
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
     struct Staging { ViewXform* h = nullptr; void* d = nullptr; size_t cap = 0 /* bytes */; hipEvent_t ev = nullptr; bool in_flight = false; };   // h: pinned + mapped, d: its device address
@@ -134,6 +135,7 @@ struct sr_target_t {
     // draw is issued again in full before anything of it can be observed (finish_target), like a draw whose tile
     // reference list overflowed.
     bool lean = false;
+    bool normal_mapping = false;   // as the device said when the draw was issued (a redraw repeats it)
     bool no_alloc = false;      // the last draw came through sr_draw_no_alloc: if it is issued again, then the same way
 };
 
@@ -347,6 +349,8 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         FragLaunch f{};
         f.idx = m->d_idx; f.verts_aos = m->d_aos; f.views = d_views; f.vis = tg->d_vis; f.color = tg->d_color; f.g = g;
         f.albedo = make_tex_desc(albedo); f.metallic = make_tex_desc(metallic); f.roughness = make_tex_desc(roughness);
+        f.normal_mapping = tg->normal_mapping && tg->tex[1] != nullptr;
+        if (f.normal_mapping) f.normal = make_tex_desc(tg->tex[1]);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv; f.flags = tg->flags;
         f.report = PassReport{b.counters, b.pending_total, nv, b.micro_spread, tg->lean ? pass_counters : nullptr};
         f.identity_model = true;
@@ -806,6 +810,7 @@ static int draw_common(sr_device dev, sr_target target, sr_mesh mesh, const void
     if (n_views == 0 || n_views > target->n_views) return fail(SR_ERR_INVALID_ARGUMENT, "n_views must be in 1..target views");
     if (ubo_stride < 204 || (ubo_stride & 3)) return fail(SR_ERR_INVALID_ARGUMENT, "ubo_stride must be >= 204 and a multiple of 4");
     if (!textures[0] || !textures[2] || !textures[3]) return fail(SR_ERR_INVALID_ARGUMENT, "albedo, metallic and roughness textures are required");
+    if (dev->normal_mapping && !textures[1]) return fail(SR_ERR_INVALID_ARGUMENT, "normal mapping is on: the normal texture is required");
     SR_HIP(hipSetDevice(dev->ordinal));
     // a finished earlier draw tells how many tile references the scene needs: grow before reuse
     if (!no_alloc && target->check_pending && hipStreamQuery(dev->stream) == hipSuccess) {
@@ -824,8 +829,9 @@ static int draw_common(sr_device dev, sr_target target, sr_mesh mesh, const void
             const volatile uint32_t* c = target->h_counters + (size_t)p * kCountersPerPass;
             lean = c[3] == 0u && c[5] == 0u;
         }
-        target->lean = lean;
+        target->lean = lean && !dev->normal_mapping;   // (the kernel that reports a lean draw's counters has no normal-mapping form)
     }
+    target->normal_mapping = dev->normal_mapping;
     target->mesh = mesh; target->mesh_verts = mesh->n_verts; target->mesh_tris = mesh->n_tris;
     for (int k = 0; k < 4; ++k) target->tex[k] = textures[k];
     target->views.resize(n_views);
@@ -854,6 +860,13 @@ int sr_draw_no_alloc(sr_device dev, sr_target target, sr_mesh mesh, const void* 
 }
 
 size_t sr_no_alloc_scratch_bytes(void) { return kStaticScratchBytes; }
+
+int sr_device_set_normal_mapping(sr_device dev, int enabled)
+{
+    if (!dev) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    dev->normal_mapping = enabled != 0;
+    return SR_OK;
+}
 
 // ---- instrumentation ----------------------------------------------------------------------------
 int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)

@@ -1238,6 +1238,7 @@ struct FragParams {
     uint32_t* color;
     FrameGeom g;
     TexDesc albedo, metallic, roughness;
+    TexDesc normal;            // read only by the kernels compiled with normal mapping
     ShadeTables tab;
     uint32_t view0;            // first view of this pass inside the target
     uint32_t paired;           // 1: the metallic and roughness maps have the same size and sampler state, so one set of footprints serves both
@@ -1258,9 +1259,11 @@ struct FragParams {
 // IDENT: the model matrix of every view of the launch is the identity (every configuration of the reference,
 // src/main.cpp:991): the products with it are skipped.  The general product with an identity matrix returns p + 0 for a
 // finite position, bit for bit, so the window-space vertices stay those of the vertex stage.
-template <bool ANISO, bool IDENT>
+// NMAP: the normal comes from the normal map (getNormalFromMap of shaders/shader.frag:35-53 with its body, which the reference has
+// commented out, restored): off unless the caller asks for it, because the reference itself shades with the interpolated normal.
+template <bool ANISO, bool IDENT, bool NMAP>
 __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx, uint32_t tri, int x, int y,
-                                       const float* dec, const float* thr, const uint32_t* lvl /* [3][kMaxMipLevels] */)
+                                       const float* dec, const float* thr, const uint32_t* lvl /* [4][kMaxMipLevels] */)
 {
     const uint32_t i0 = p.idx[3 * (size_t)tri], i1 = p.idx[3 * (size_t)tri + 1], i2 = p.idx[3 * (size_t)tri + 2];
     const float4 a0 = p.verts[2 * (size_t)i0], b0 = p.verts[2 * (size_t)i0 + 1];
@@ -1346,6 +1349,29 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     float wp[3], N[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { wp[k] = fmaf(p2, w2[k], fmaf(p1, w1[k], p0 * w0[k])); N[k] = fmaf(p2, n2[k], fmaf(p1, n1[k], p0 * n0[k])); }
+    if constexpr (NMAP) {
+        // dFdx / dFdy of WorldPos: this triangle's world position at the quad's top-left, top-right and bottom-left pixel centres
+        const float a0q = fmaf(oy, q0y, fmaf(ox, q0x, q0)), a1q = fmaf(oy, q1y, fmaf(ox, q1x, q1)), a2q = fmaf(oy, q2y, fmaf(ox, q2x, q2));
+        float Q1[3], Q2[3], tn[3], Nn[3], T[3], B[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float w00 = fmaf(a2q, w2[k], fmaf(a1q, w1[k], a0q * w0[k])) * r00;
+            const float w10 = fmaf(a2q + q2x, w2[k], fmaf(a1q + q1x, w1[k], (a0q + q0x) * w0[k])) * r10;
+            const float w01 = fmaf(a2q + q2y, w2[k], fmaf(a1q + q1y, w1[k], (a0q + q0y) * w0[k])) * r01;
+            Q1[k] = w10 - w00; Q2[k] = w01 - w00;
+        }
+        if constexpr (ANISO) sample_texture_aniso<3>(p.normal, lvl + 3 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, tn);
+        else sample_texture<3>(p.normal, lvl + 3 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, tn);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { tn[k] = tn[k] * 2.0f - 1.0f; T[k] = Q1[k] * dvdy - Q2[k] * dvdx; }
+        normalize3(N, Nn);
+        normalize3(T, T);
+        B[0] = Nn[1] * T[2] - Nn[2] * T[1]; B[1] = Nn[2] * T[0] - Nn[0] * T[2]; B[2] = Nn[0] * T[1] - Nn[1] * T[0];
+        normalize3(B, B);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) N[k] = T[k] * tn[0] - B[k] * tn[1] + Nn[k] * tn[2];   // mat3(T, -normalize(cross(N, T)), N) * tangentNormal
+        normalize3(N, N);
+    }
     float alb[3], met[1], rgh[1], rgb[3];
     if constexpr (ANISO) {
         sample_texture_aniso<3>(p.albedo, lvl, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
@@ -1386,12 +1412,12 @@ __device__ inline void report_pass(const PassReport& r, uint32_t lane)
     }
 }
 
-template <int S, bool ANISO, bool IDENT>
+template <int S, bool ANISO, bool IDENT, bool NMAP>
 __device__ __forceinline__ void fragment_body(const FragParams& p)
 {
     __shared__ float s_dec[256];
     __shared__ float s_thr[256];
-    __shared__ uint32_t s_lvl[3 * kMaxMipLevels];
+    __shared__ uint32_t s_lvl[4 * kMaxMipLevels];
     __shared__ uint32_t s_any;
     const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x;
     const int lx = (int)(blockIdx.x * blockDim.x + threadIdx.x), ly = (int)(blockIdx.y * blockDim.y + threadIdx.y);
@@ -1420,9 +1446,9 @@ __device__ __forceinline__ void fragment_body(const FragParams& p)
         s_dec[tid] = p.tab.decode[tid];
         s_thr[tid] = tid < 255u ? p.tab.thresh[tid] : 3.0e38f;
     }
-    if (tid < 3u * kMaxMipLevels) {
+    if (tid < (NMAP ? 4u : 3u) * kMaxMipLevels) {
         const uint32_t m = tid / kMaxMipLevels, l = tid % kMaxMipLevels;
-        s_lvl[tid] = m == 0 ? p.albedo.level_off[l] : m == 1 ? p.metallic.level_off[l] : p.roughness.level_off[l];
+        s_lvl[tid] = m == 0 ? p.albedo.level_off[l] : m == 1 ? p.metallic.level_off[l] : m == 2 ? p.roughness.level_off[l] : p.normal.level_off[l];
     }
     __syncthreads();
     if (!inside) return;
@@ -1441,7 +1467,7 @@ __device__ __forceinline__ void fragment_body(const FragParams& p)
             for (int k = 0; k < s; ++k) if (k == prev) c = col[k];
             col[s] = c;
         } else {
-            col[s] = shade_pixel<ANISO, IDENT>(p, vx, ids[s], x, y, s_dec, s_thr, s_lvl);
+            col[s] = shade_pixel<ANISO, IDENT, NMAP>(p, vx, ids[s], x, y, s_dec, s_thr, s_lvl);
         }
     }
     uint32_t outc;
@@ -1464,17 +1490,17 @@ __device__ __forceinline__ void fragment_body(const FragParams& p)
     p.color[pix] = outc;
 }
 
-template <int S, bool ANISO, bool IDENT>
+template <int S, bool ANISO, bool IDENT, bool NMAP>
 __global__ __launch_bounds__(256) SR_FRAG_ATTR void fragment_kernel(FragParams p)
 {
-    fragment_body<S, ANISO, IDENT>(p);
+    fragment_body<S, ANISO, IDENT, NMAP>(p);
 }
 // the same, for a lean draw: the launch's first workgroup reports the counters of the pass before it turns to its pixels
 template <int S, bool ANISO, bool IDENT>
 __global__ __launch_bounds__(256) SR_FRAG_ATTR void fragment_report_kernel(FragParams p)
 {
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.y * blockDim.x + threadIdx.x < 64u) report_pass(p.report, lane_id());
-    fragment_body<S, ANISO, IDENT>(p);
+    fragment_body<S, ANISO, IDENT, false>(p);
 }
 
 // =================================================================================================
@@ -1683,21 +1709,25 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
     if (!f.n_views) return;
     FragParams p;
     p.idx = f.idx; p.verts = (const float4*)f.verts_aos; p.views = f.views; p.vis = (const unsigned long long*)f.vis; p.color = f.color;
-    p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness;
+    p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness; p.normal = f.normal;
     p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.flags = f.flags; p.report = f.report;
     const TexDesc &m = f.metallic, &r = f.roughness;
     p.paired = m.w == r.w && m.h == r.h && m.levels == r.levels && m.min_lod == r.min_lod && m.max_lod == r.max_lod && m.bias == r.bias &&
                std::memcmp(m.level_off, r.level_off, sizeof m.level_off) == 0;
     const dim3 grid(div_up((uint32_t)f.g.rw, kFragBlockW), div_up((uint32_t)f.g.rh, kFragBlockH), f.n_views), block(kFragBlockW, kFragBlockH);
     // the anisotropic footprint is compiled in only when a bound sampler asks for it
-    const bool aniso = f.albedo.max_aniso > 1.0f || f.metallic.max_aniso > 1.0f || f.roughness.max_aniso > 1.0f;
+    const bool aniso = f.albedo.max_aniso > 1.0f || f.metallic.max_aniso > 1.0f || f.roughness.max_aniso > 1.0f ||
+                       (f.normal_mapping && f.normal.max_aniso > 1.0f);
     const bool report = f.report.host_counters != nullptr;
 #define SR_LAUNCH_FRAGMENT(S, A, I)                                                          \
     do {                                                                                      \
         if (report) fragment_report_kernel<S, A, I><<<grid, block, 0, st>>>(p);               \
-        else fragment_kernel<S, A, I><<<grid, block, 0, st>>>(p);                             \
+        else fragment_kernel<S, A, I, false><<<grid, block, 0, st>>>(p);                      \
     } while (0)
-    if (f.g.samples == 1) {
+    if (f.normal_mapping) {   // (never a lean draw; the general model-matrix form)
+        if (f.g.samples == 1) { if (aniso) fragment_kernel<1, true, false, true><<<grid, block, 0, st>>>(p); else fragment_kernel<1, false, false, true><<<grid, block, 0, st>>>(p); }
+        else { if (aniso) fragment_kernel<4, true, false, true><<<grid, block, 0, st>>>(p); else fragment_kernel<4, false, false, true><<<grid, block, 0, st>>>(p); }
+    } else if (f.g.samples == 1) {
         if (aniso && f.identity_model) SR_LAUNCH_FRAGMENT(1, true, true);
         else if (aniso) SR_LAUNCH_FRAGMENT(1, true, false);
         else if (f.identity_model) SR_LAUNCH_FRAGMENT(1, false, true);

@@ -13,6 +13,8 @@ struct FragLaunch {
     uint32_t* color;
     FrameGeom g;
     TexDesc albedo, metallic, roughness;
+    TexDesc normal;            // used when normal_mapping is set
+    bool normal_mapping;       // shade with the normal map's normals (the reference's getNormalFromMap with its body restored)
     const float* decode;
     const float* thresh;
     uint32_t view0, n_views;

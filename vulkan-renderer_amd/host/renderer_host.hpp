@@ -123,6 +123,8 @@ public:
     GPUDevice(GPUDevice&&) = delete;
     GPUDevice& operator=(GPUDevice&&) = delete;
     void wait_idle() noexcept { sr_device_synchronize(device_); }
+    // shade with the normal map (shaders/shader.frag:35-53 with its commented-out body restored); off by default, as in the reference
+    void set_normal_mapping(bool enabled) noexcept { sr_device_set_normal_mapping(device_, enabled ? 1 : 0); }
     [[nodiscard]] sr_device device() const noexcept { return device_; }
 
 private:

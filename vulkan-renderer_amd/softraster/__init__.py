@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "sr_target_readback", "sr_draw", "sr_draw_get_stats", "sr_profile_enable", "sr_profile_get", "sr_debug_vertex_stage",
     "sr_texture_size", "sr_texture_create_from_file", "sr_image_read_file", "sr_image_free",
     "sr_model_load", "sr_model_mesh_count", "sr_model_mesh", "sr_model_destroy", "sr_model_read_file", "sr_model_mesh_data",
-    "sr_draw_no_alloc", "sr_no_alloc_scratch_bytes",
+    "sr_draw_no_alloc", "sr_no_alloc_scratch_bytes", "sr_device_set_normal_mapping",
 )
 
 
@@ -118,6 +118,7 @@ def load_library():
     L.sr_draw.argtypes = [vp, vp, vp, vp, u32, sz, C.POINTER(vp)]
     L.sr_draw_no_alloc.argtypes = [vp, vp, vp, vp, u32, sz, C.POINTER(vp)]
     L.sr_no_alloc_scratch_bytes.restype = sz
+    L.sr_device_set_normal_mapping.argtypes = [vp, C.c_int]
     L.sr_draw_get_stats.argtypes = [vp, vp, C.POINTER(DrawStats)]
     L.sr_profile_enable.argtypes = [vp, C.c_int]
     L.sr_profile_get.argtypes = [vp, C.POINTER(StageTimes)]
@@ -173,6 +174,11 @@ class Device:
         _check(self._lib.sr_device_synchronize(self._h), "sr_device_synchronize")
 
     wait_idle = synchronize  # vkh::GPUDevice::wait_idle, src/main.cpp:170
+
+    def set_normal_mapping(self, enabled: bool):
+        """Draws issued from now on shade with the normal map's normals (shaders/shader.frag:35-53 with the body the reference
+        has commented out restored); off by default, as in the reference."""
+        _check(self._lib.sr_device_set_normal_mapping(self._h, int(enabled)), "sr_device_set_normal_mapping")
 
     def profile(self, enabled: bool):
         _check(self._lib.sr_profile_enable(self._h, int(enabled)), "sr_profile_enable")
