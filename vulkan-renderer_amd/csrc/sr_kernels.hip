@@ -36,25 +36,38 @@ struct BeginWork {
     int rw, rh, S;
     uint32_t view0, n_views;     // views of the pass
     uint4* zero4; size_t n_zero4;   // binning counters to zero
+    uint32_t clear_group;           // flag blocks a wave looks at per turn (clear_flagged_blocks)
 };
-// clears the two pixels of clear item `item` of the pass (items: views x rows x pixel pairs of a row) if their block is flagged
-__device__ inline void clear_item(const BeginWork& w, size_t item)
+// The visibility words of the flagged blocks of the pass's views are cleared wave by wave: a wave looks at the flags of
+// w.clear_group consecutive blocks per turn (one lane each; 1 for a small frame, whose few blocks should be spread over many waves,
+// up to 8 for a large one) and clears the flagged ones of them one after the other, 64 words (512 contiguous bytes of a row) per
+// store instruction.  A frame that is mostly background costs little more than reading its flags.
+__device__ inline void clear_flagged_blocks(const BeginWork& w, size_t wave_id, size_t n_waves, uint32_t lane)
 {
-    const uint32_t pairs = (uint32_t)(w.rw + 1) >> 1;
-    const size_t per_view = (size_t)pairs * (uint32_t)w.rh;
-    const uint32_t view = w.view0 + (uint32_t)(item / per_view);
-    const uint32_t rem = (uint32_t)(item % per_view);
-    const int y = (int)(rem / pairs), x = (int)(rem % pairs) * 2;
-    if (w.flags.of(view, x, y) == 0u) return;
-    unsigned long long* cell = w.vis + (((size_t)view * w.rh + y) * w.rw + x) * w.S;
-    const int n = (x + 1 < w.rw ? 2 : 1) * w.S;
-    for (int i = 0; i < n; ++i) cell[i] = kVisClear;
+    const uint32_t per_view = (uint32_t)(w.flags.nbx * w.flags.nby);
+    const size_t n_blocks = (size_t)per_view * w.n_views;
+    const uint32_t log2_s = w.S == 4 ? 2u : 0u;                                   // 1 or 4 samples
+    const uint32_t row_shift = 5u + log2_s, block_words = (kFlagBlockW * kFlagBlockH) << log2_s;
+    static_assert(kFlagBlockW == 32, "a block row is 32 pixels");
+    for (size_t first = wave_id * w.clear_group; first < n_blocks; first += n_waves * w.clear_group) {
+        const size_t mine = first + lane;
+        const uint32_t flag = lane < w.clear_group && mine < n_blocks ? w.flags.flags[(size_t)w.view0 * per_view + mine] : 0u;
+        for (uint64_t todo = __ballot(flag != 0u); todo; todo &= todo - 1ull) {
+            const size_t blk = first + (uint32_t)(__ffsll((long long)todo) - 1);
+            const uint32_t view = w.view0 + (uint32_t)(blk / per_view), in_view = (uint32_t)(blk % per_view);
+            const int x0 = (int)(in_view % (uint32_t)w.flags.nbx) * (int)kFlagBlockW, y0 = (int)(in_view / (uint32_t)w.flags.nbx) * (int)kFlagBlockH;
+            unsigned long long* origin = w.vis + ((((size_t)view * w.rh + y0) * w.rw + x0) << log2_s);
+            for (uint32_t word = lane; word < block_words; word += 64u) {
+                const uint32_t row = word >> row_shift, col = word & ((1u << row_shift) - 1u);
+                if (x0 + (int)(col >> log2_s) < w.rw && y0 + (int)row < w.rh) origin[(((size_t)row * w.rw) << log2_s) + col] = kVisClear;
+            }
+        }
+    }
 }
 __device__ inline void begin_work(const BeginWork& w, size_t gtid, size_t gstride)
 {
     for (size_t i = gtid; i < w.n_zero4; i += gstride) w.zero4[i] = make_uint4(0u, 0u, 0u, 0u);
-    const size_t items = (size_t)(((uint32_t)w.rw + 1u) >> 1) * (uint32_t)w.rh * w.n_views;
-    for (size_t i = gtid; i < items; i += gstride) clear_item(w, i);
+    clear_flagged_blocks(w, gtid >> 6, gstride >> 6, (uint32_t)(gtid & 63u));   // (workgroups are whole waves: 256 work-items)
 }
 
 __global__ __launch_bounds__(256) void begin_pass_kernel(BeginWork w, const uint4* __restrict__ views_src, uint4* __restrict__ views_dst, uint32_t n_views4)
@@ -637,25 +650,39 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ micro_spread,
                                                     uint32_t* __restrict__ host_counters)
 {
+    // chunks of kScanChunk counts: loaded side by side into LDS, eight consecutive ones summed and scanned by each work-item, the
+    // 1024 partial sums scanned by the workgroup, offsets written side by side; the running total carries over to the next chunk
+    constexpr uint32_t kPer = 8, kScanChunk = 1024u * kPer;
+    __shared__ uint32_t s_cnt[kScanChunk];
     __shared__ uint32_t part[1024];
     __shared__ uint32_t s_micro_total;
     if (threadIdx.x == 0) s_micro_total = 0u;
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t beg = min(tid * per, n), end = min(beg + per, n);
-    uint32_t s = 0;
-    for (uint32_t i = beg; i < end; ++i) s += count_a[i] + count_b[i];
-    part[tid] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {   // Hillis-Steele inclusive scan
-        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += kScanChunk) {
+        const uint32_t m = min(kScanChunk, n - base);
+        __syncthreads();   // the previous chunk's tables are no longer in use
+        for (uint32_t i = tid; i < kScanChunk; i += 1024u) s_cnt[i] = i < m ? count_a[base + i] + count_b[base + i] : 0u;
         __syncthreads();
-        part[tid] += v;
+        uint32_t s = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) s += s_cnt[tid * kPer + k];
+        part[tid] = s;
         __syncthreads();
+        for (uint32_t d = 1; d < 1024u; d <<= 1) {   // Hillis-Steele inclusive scan
+            const uint32_t v = tid >= d ? part[tid - d] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        uint32_t run = carry + part[tid] - s;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) { const uint32_t c = s_cnt[tid * kPer + k]; s_cnt[tid * kPer + k] = run; run += c; }
+        carry += part[1023];
+        __syncthreads();
+        for (uint32_t i = tid; i < m; i += 1024u) offset[base + i] = s_cnt[i];
     }
-    uint32_t run = part[tid] - s;
-    for (uint32_t i = beg; i < end; ++i) { offset[i] = run; run += count_a[i] + count_b[i]; }
-    if (tid == 1023u) { offset[n] = part[1023]; counters[kCtrRefs] = part[1023]; }
+    if (tid == 1023u) { offset[n] = carry; counters[kCtrRefs] = carry; }
     // micro-triangles resolved by the set-up blocks (instrumentation)
     uint32_t micro = tid < kMicroSpread ? micro_spread[tid * kMicroSpreadStride] : 0u;
     for (int o = 32; o > 0; o >>= 1) micro += (uint32_t)__shfl_down((int)micro, o);
@@ -666,7 +693,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
         // stream has been synchronised): total references, -, unprojectable, binned, direct, -, clipped
         uint32_t binned = 0;
         for (uint32_t v = 0; v < n_views; ++v) binned += pending_total[v];
-        host_counters[0] = part[1023]; host_counters[1] = 0u; host_counters[2] = counters[kCtrUnprojectable];
+        host_counters[0] = carry; host_counters[1] = 0u; host_counters[2] = counters[kCtrUnprojectable];
         host_counters[3] = binned; host_counters[4] = s_micro_total; host_counters[5] = counters[kCtrClipListed];
         host_counters[6] = counters[kCtrClipped];
     }
@@ -1583,19 +1610,31 @@ void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* 
     split_positions_kernel<<<div_up(plane_stride(n), 256), 256, 0, st>>>((const float4*)aos, n, px, py, pz);
 }
 
+static uint32_t clear_group(const BlockFlags& flags, uint32_t n_views)
+{
+    return (uint32_t)std::min<size_t>(std::max<size_t>((size_t)flags.nbx * flags.nby * n_views / 4096, 1), 8);
+}
 static BeginWork make_begin_work(uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0, uint32_t n_views, void* zero16, size_t zero_bytes)
 {
     BeginWork w;
     w.vis = (unsigned long long*)vis; w.flags = flags; w.rw = g.rw; w.rh = g.rh; w.S = g.samples; w.view0 = view0; w.n_views = n_views;
     w.zero4 = (uint4*)zero16; w.n_zero4 = zero_bytes / 16;
+    w.clear_group = clear_group(flags, n_views);
     return w;
+}
+
+// workgroups for the start of a pass: a wave per group of flag blocks (clear_flagged_blocks), a work-item per 16 bytes to zero
+static uint32_t begin_blocks(const BlockFlags& flags, uint32_t n_views, size_t zero_bytes)
+{
+    const uint32_t group = clear_group(flags, n_views);
+    const size_t wave_turns = ((size_t)flags.nbx * flags.nby * n_views + group - 1) / group;
+    return (uint32_t)std::min<size_t>(std::max<size_t>({(wave_turns + 3) / 4, (zero_bytes / 16 + 255) / 256, (size_t)1}), 65536);
 }
 
 void launch_begin_pass(hipStream_t st, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0, uint32_t n_views,
                        void* zero16, size_t zero_bytes, const void* views_src, void* views_dst, size_t views_bytes)
 {
-    const size_t items = (size_t)((g.rw + 1) / 2) * g.rh * n_views;
-    const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>((items + 255) / 256, 1), 65536);
+    const uint32_t blocks = begin_blocks(flags, n_views, zero_bytes);
     begin_pass_kernel<<<blocks, 256, 0, st>>>(make_begin_work(vis, flags, g, view0, n_views, zero16, zero_bytes),
                                               (const uint4*)views_src, (uint4*)views_dst, (uint32_t)(views_bytes / 16));
 }
@@ -1608,8 +1647,7 @@ bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, c
     ViewPack pack;
     std::memcpy(pack.v, host_views, (size_t)n_views * sizeof(ViewXform));
     // enough workgroups for the clearing part too when the mesh is small (a workgroup past the last vertex group only clears)
-    const size_t items = (size_t)((g.rw + 1) / 2) * g.rh * n_views;
-    const uint32_t for_clearing = (uint32_t)std::min<size_t>(div_up((uint32_t)std::min<size_t>(items, 1u << 30), 1024u), 4096u);
+    const uint32_t for_clearing = begin_blocks(flags, n_views, zero_bytes);
     vertex_begin_kernel<<<std::max(div_up(n, kFusedVertexGroup * 256u), for_clearing), 256, 0, st>>>(px, py, pz, n, pack, views_dst, W, H, out,
                                                                        make_begin_work(vis, flags, g, view0, n_views, zero16, zero_bytes));
     return true;
