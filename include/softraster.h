@@ -160,7 +160,10 @@ SR_API int sr_target_create(sr_device dev, int width, int height, int samples, u
                             const sr_rect* rect, sr_target* out);
 SR_API int sr_target_destroy(sr_device dev, sr_target target);
 /* Render colour into caller-owned device memory (n_views * rect.height * rect.width * 4 bytes)
- * instead of the target's own buffer, e.g. a tensor handed to a collective.  NULL restores it. */
+ * instead of the target's own buffer, e.g. a tensor handed to a collective.  NULL restores it.
+ * A draw stores only the pixels whose colour changes: parts of the frame that were background in the last
+ * draw and still are keep the clear colour they already hold.  A caller that writes into the bound memory itself
+ * binds it again before the next draw (the draw after a bind stores every pixel). */
 SR_API int sr_target_bind_color(sr_device dev, sr_target target, void* device_ptr);
 /* No reference counterpart (the reference only presents): copy one view's result to the host. */
 SR_API int sr_target_readback(sr_device dev, sr_target target, int kind, uint32_t view,

@@ -645,6 +645,22 @@ def test_colour_bound_to_caller_memory(sr, oracle, device):
             tgt.destroy()
         frame = np.empty((H, W, 4), np.uint8)
         assert hip.hipMemcpy(frame.ctypes.data, frame_mem, frame.nbytes, 2) == 0     # hipMemcpyDeviceToHost
+        # a draw stores only the pixels whose colour changes; memory the caller has written into is bound again, and the
+        # next draw then stores every pixel: scribble over the frame, bind, draw twice (the second stores nothing new)
+        tgt = sr.RenderTarget(device, W, H)
+        tgt.bind_color(frame_mem.value)
+        sr.draw(device, tgt, mesh, ubo, tex)
+        device.synchronize()
+        scribble = np.full((H, W, 4), 0x5A, np.uint8)
+        assert hip.hipMemcpy(frame_mem, scribble.ctypes.data, scribble.nbytes, 1) == 0   # hipMemcpyHostToDevice
+        tgt.bind_color(frame_mem.value)
+        for _ in range(2):
+            sr.draw(device, tgt, mesh, ubo, tex)
+            device.synchronize()
+            again = np.empty((H, W, 4), np.uint8)
+            assert hip.hipMemcpy(again.ctypes.data, frame_mem, again.nbytes, 2) == 0
+            assert np.array_equal(again, frame)
+        tgt.destroy()
         assert hip.hipFree(frame_mem) == 0
         ref = oracle.draw(ubo, verts, idx, images, W, H)
         frac, worst = util.color_match_fraction(frame, ref["bgra"], 1)

@@ -116,7 +116,7 @@ struct sr_target_t {
     uint64_t* d_vis = nullptr;
     uint32_t* d_color_own = nullptr;
     uint32_t* d_color = nullptr;
-    BlockFlags flags{nullptr, 0, 0};   // which blocks of the visibility buffer hold anything (sr_device.h); all set at creation
+    BlockFlags flags{nullptr, nullptr, 0, 0};   // per block of every view: visibility words written / colour not clear (sr_device.h); all set at creation
     // the last draw, kept so that it can be re-issued if the reference list was too small; mesh and textures are
     // referenced only while check_pending is set (destroying one of them resolves the draw first)
     bool drawn = false, check_pending = false;
@@ -330,7 +330,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr, dev->fill_blocks);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, v0, ev ? ev[3] : nullptr, !tg->lean, dev->fill_blocks);
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, tg->flags, v0, ev ? ev[3] : nullptr, !tg->lean, dev->fill_blocks);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
@@ -338,12 +338,12 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
             if (ev) { SR_HIP(hipEventRecord(ev[5], st)); SR_HIP(hipEventRecord(ev[6], st)); }
         } else {
             // (before the scan kernel, which reports the counters to the host)
-            launch_near_clip(st, m->d_idx, m->n_tris, m->px, m->py, m->pz, d_views, g, clip, b, tg->d_vis, v0);
+            launch_near_clip(st, m->d_idx, m->n_tris, m->px, m->py, m->pz, d_views, g, clip, b, tg->d_vis, tg->flags, v0);
             launch_scan(st, b, nv * n_tiles, nv, pass_counters);
             if (ev) SR_HIP(hipEventRecord(ev[5], st));
             launch_fill(st, g, b, m->n_tris, nv);
             if (ev) SR_HIP(hipEventRecord(ev[6], st));
-            launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, v0, nv);
+            launch_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, tg->flags, v0, nv);
         }
         if (ev) SR_HIP(hipEventRecord(ev[7], st));
         FragLaunch f{};
@@ -727,8 +727,8 @@ int sr_target_create(sr_device dev, int width, int height, int samples, uint32_t
     t->flags.nbx = (g.rw + (int)kFlagBlockW - 1) / (int)kFlagBlockW;
     t->flags.nby = (g.rh + (int)kFlagBlockH - 1) / (int)kFlagBlockH;
     const size_t flag_bytes = (size_t)n_views * t->flags.nbx * t->flags.nby * 4;
-    e = hipMalloc((void**)&t->flags.flags, flag_bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(t->flags.flags, 0x01, flag_bytes, dev->stream);
+    e = hipMalloc((void**)&t->flags.flags, 2 * flag_bytes);   // both planes; everything flagged: the first draw clears every word and stores every pixel
+    if (e == hipSuccess) { t->flags.color_dirty = t->flags.flags + flag_bytes / 4; e = hipMemsetAsync(t->flags.flags, 0x01, 2 * flag_bytes, dev->stream); }
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) { (void)hipFree(t->d_vis); (void)hipFree(t->d_color_own); (void)hipFree(t->flags.flags); delete t; SR_HIP(e); }
     // room for the counters of a one-pass draw, so that such a draw allocates nothing here
@@ -762,6 +762,8 @@ int sr_target_bind_color(sr_device dev, sr_target target, void* device_ptr)
     int rc = finish_target(dev, target);
     if (rc != SR_OK) return rc;
     target->d_color = device_ptr ? (uint32_t*)device_ptr : target->d_color_own;
+    // nothing is known about what this memory holds: every block's colour has to be stored by the next draw
+    SR_HIP(hipMemsetAsync(target->flags.color_dirty, 0x01, (size_t)target->n_views * target->flags.nbx * target->flags.nby * 4, dev->stream));
     return SR_OK;
 }
 

@@ -62,6 +62,7 @@ __device__ inline void clear_flagged_blocks(const BeginWork& w, size_t wave_id, 
                 if (x0 + (int)(col >> log2_s) < w.rw && y0 + (int)row < w.rh) origin[(((size_t)row * w.rw) << log2_s) + col] = kVisClear;
             }
         }
+        if (flag != 0u) w.flags.flags[(size_t)w.view0 * per_view + mine] = 0u;   // down again: the kernels of this draw set it where they write
     }
 }
 __device__ inline void begin_work(const BeginWork& w, size_t gtid, size_t gstride)
@@ -316,8 +317,8 @@ __device__ inline uint32_t xcd_runs(uint32_t b, uint32_t n)
 // atomic add per block that has any).
 template <int S, bool VIEW_LOOP>
 __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
-                                                    FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, uint32_t view0,
-                                                    uint32_t n_views, uint32_t views_per_block)
+                                                    FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, BlockFlags flags,
+                                                    uint32_t view0, uint32_t n_views, uint32_t views_per_block)
 {
     __shared__ uint32_t s_wave[kSetupTris * 4];
     __shared__ uint32_t s_micro[4];
@@ -419,7 +420,15 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             int x0, y0, npx, npy;
             sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
             const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
-            if (micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_view, g)) ++n_micro;
+            if (micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_view, g)) {
+                ++n_micro;
+                // the blocks the box reaches into now hold something (one block as a rule, four at most: a box is smaller than a block)
+                const uint32_t bx0 = (uint32_t)(x0 - g.rx) / kFlagBlockW, bx1 = (uint32_t)(x0 + npx - 1 - g.rx) / kFlagBlockW;
+                const uint32_t by0 = (uint32_t)(y0 - g.ry) / kFlagBlockH, by1 = (uint32_t)(y0 + npy - 1 - g.ry) / kFlagBlockH;
+                flags.at(view0 + view, bx0, by0) = 1u;
+                if (bx1 != bx0) flags.at(view0 + view, bx1, by0) = 1u;
+                if (by1 != by0) { flags.at(view0 + view, bx0, by1) = 1u; if (bx1 != bx0) flags.at(view0 + view, bx1, by1) = 1u; }
+            }
         }
     }
     if (n_unproj) atomicAdd(&b.counters[kCtrUnprojectable], n_unproj);   // rare
@@ -786,7 +795,7 @@ __device__ inline void raster_pixel32(const TriSetup& ts, uint32_t tri, int x, i
 template <int TL2, int S, int TPB>
 __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                      FrameGeom g, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ refs,
-                                                     uint32_t ref_capacity, unsigned long long* __restrict__ vis, uint32_t view0)
+                                                     uint32_t ref_capacity, unsigned long long* __restrict__ vis, BlockFlags flags, uint32_t view0)
 {
     constexpr int T = 1 << TL2;
     constexpr int kSmall = 16;   // bounding boxes up to this many pixels are walked by one lane
@@ -912,8 +921,13 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
     for (int i = tid; i < T * T * S; i += TPB) {
         const int s = i % S, p = i / S, lx = p & (T - 1), ly = p >> TL2;
         // merge with what micro-triangles already resolved in HBM; untouched samples cost nothing
-        if (lx < tw && ly < th && tile[i] != kVisClear)
-            atomicMin(&out[((size_t)(py0 - g.ry + ly) * g.rw + (px0 - g.rx + lx)) * S + s], tile[i]);
+        const bool covered = lx < tw && ly < th && tile[i] != kVisClear;
+        if (covered) atomicMin(&out[((size_t)(py0 - g.ry + ly) * g.rw + (px0 - g.rx + lx)) * S + s], tile[i]);
+        // the flag of the block: stored by the first lane of every run of covered samples of one block (a wave's 64 samples lie in
+        // one row of the tile, in one or two blocks)
+        const int bid = ((py0 - g.ry + ly) / (int)kFlagBlockH) * flags.nbx + (px0 - g.rx + lx) / (int)kFlagBlockW;
+        const int prev_bid = __shfl_up(covered ? bid : -1, 1);
+        if (covered && (lane == 0u || prev_bid != bid)) flags.flags[(size_t)(view0 + view) * flags.nbx * flags.nby + bid] = 1u;
     }
 }
 
@@ -931,7 +945,7 @@ template <int S>
 __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris,
                                                         const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                         const ViewXform* __restrict__ views, FrameGeom g, ClipList clip, uint32_t* __restrict__ counters,
-                                                        unsigned long long* __restrict__ vis, uint32_t view0)
+                                                        unsigned long long* __restrict__ vis, BlockFlags flags, uint32_t view0)
 {
     const uint32_t n = min(counters[kCtrClipListed], clip.capacity);
     const uint32_t lane = lane_id();
@@ -974,6 +988,8 @@ __global__ __launch_bounds__(256) void near_clip_kernel(const uint32_t* __restri
                         if (narrow) raster_pixel32<S>(ts, tri, x, y, cell);
                         else raster_pixel<S>(ts, tri, x, y, cell);
                     }
+                    // the blocks under the four corners of the 8 x 8 step (all the blocks it reaches into) may hold something now
+                    if (lane < 4u) flags.of(view0 + view, min(bx + 7 * (int)(lane & 1u), x1) - g.rx, min(by + 7 * (int)(lane >> 1), y1) - g.ry) = 1u;
                 }
         }
     }
@@ -1445,30 +1461,26 @@ __device__ __forceinline__ void fragment_body(const FragParams& p)
     __shared__ float s_dec[256];
     __shared__ float s_thr[256];
     __shared__ uint32_t s_lvl[4 * kMaxMipLevels];
-    __shared__ uint32_t s_any;
     const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x;
     const int lx = (int)(blockIdx.x * blockDim.x + threadIdx.x), ly = (int)(blockIdx.y * blockDim.y + threadIdx.y);
     const uint32_t view = blockIdx.z;
     const bool inside = lx < p.g.rw && ly < p.g.rh;
     const size_t pix = ((size_t)(p.view0 + view) * p.g.rh + (inside ? ly : 0)) * p.g.rw + (inside ? lx : 0);
-    uint32_t ids[S];
-    bool any = false;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        ids[s] = inside ? (uint32_t)p.vis[pix * S + s] : kNoTri;
-        any = any || ids[s] != kNoTri;
-    }
-    // a workgroup over nothing but background (most of them, in a frame like the benchmark's) stores the clear colour
-    // and leaves before the tables are loaded
-    if (tid == 0) s_any = 0u;
-    __syncthreads();
-    if (__ballot(any) != 0ull && lane_id() == 0u) s_any = 1u;
-    __syncthreads();
-    if (tid == 0) p.flags.at(p.view0 + view, blockIdx.x, blockIdx.y) = s_any;   // what the next draw has to clear
-    if (s_any == 0u) {
-        if (inside) p.color[pix] = kColorClear;
+    // A workgroup over a block that no kernel of this draw wrote a visibility word of (most of them, in a frame like the
+    // benchmark's) reads nothing: it stores the clear colour, if the block's colour is not known to be that already, and leaves.
+    uint32_t& dirty = p.flags.dirty_at(p.view0 + view, blockIdx.x, blockIdx.y);
+    if (p.flags.at(p.view0 + view, blockIdx.x, blockIdx.y) == 0u) {   // the same for the whole workgroup
+        if (dirty != 0u) {
+            if (inside) p.color[pix] = kColorClear;
+            __syncthreads();   // (every work-item has read the flag)
+            if (tid == 0) dirty = 0u;
+        }
         return;
     }
+    if (tid == 0) dirty = 1u;
+    uint32_t ids[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) ids[s] = inside ? (uint32_t)p.vis[pix * S + s] : kNoTri;
     if (tid < 256u) {   // (always: the launcher uses kFragBlockW x kFragBlockH; a different shape must not index past the tables)
         s_dec[tid] = p.tab.decode[tid];
         s_thr[tid] = tid < 255u ? p.tab.thresh[tid] : 3.0e38f;
@@ -1677,7 +1689,8 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
 static inline uint32_t chunk_grid(const BinBuffers& b) { return std::min<uint32_t>(std::max<uint32_t>(b.n_blocks, 1u), 1024u); }
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
-                  const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0, hipEvent_t between, bool bin, uint32_t fill_blocks)
+                  const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags, uint32_t view0, hipEvent_t between,
+                  bool bin, uint32_t fill_blocks)
 {
     if (!n_tris || !n_views) return;
     // a workgroup takes every view of the pass for its triangles, unless the mesh is too small to fill the chip that way
@@ -1685,11 +1698,11 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
     const uint32_t views_per_block = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views);
     const dim3 grid(grid_x, div_up(n_views, views_per_block));
     if (views_per_block == 1) {
-        if (g.samples == 1) setup_kernel<1, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0, n_views, 1u);
-        else setup_kernel<4, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0, n_views, 1u);
+        if (g.samples == 1) setup_kernel<1, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u);
+        else setup_kernel<4, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u);
     } else {
-        if (g.samples == 1) setup_kernel<1, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0, n_views, views_per_block);
-        else setup_kernel<4, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, view0, n_views, views_per_block);
+        if (g.samples == 1) setup_kernel<1, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block);
+        else setup_kernel<4, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block);
     }
     if (between) (void)hipEventRecord(between, st);
     if (!bin) return;
@@ -1699,12 +1712,13 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
 }
 
 void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const float* px, const float* py, const float* pz,
-                      const ViewXform* views, const FrameGeom& g, const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0)
+                      const ViewXform* views, const FrameGeom& g, const ClipList& clip, const BinBuffers& b, uint64_t* vis, const BlockFlags& flags,
+                      uint32_t view0)
 {
     if (!n_tris) return;
     // the list is empty in any ordinary frame; five hundred waves share the pieces of a long one
-    if (g.samples == 1) near_clip_kernel<1><<<128, 256, 0, st>>>(idx, n_tris, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, view0);
-    else near_clip_kernel<4><<<128, 256, 0, st>>>(idx, n_tris, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, view0);
+    if (g.samples == 1) near_clip_kernel<1><<<128, 256, 0, st>>>(idx, n_tris, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, flags, view0);
+    else near_clip_kernel<4><<<128, 256, 0, st>>>(idx, n_tris, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, flags, view0);
 }
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters)
@@ -1720,17 +1734,17 @@ void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32
 }
 
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                   uint64_t* vis, uint32_t view0, uint32_t n_views)
+                   uint64_t* vis, const BlockFlags& flags, uint32_t view0, uint32_t n_views)
 {
     if (!n_views) return;
     const dim3 grid((uint32_t)(g.tiles_x * g.tiles_y), n_views);
     unsigned long long* v = (unsigned long long*)vis;
-    if (g.samples == 1 && g.tile_log2 == 6) raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
-    else if (g.samples == 1 && g.tile_log2 == 5) raster_kernel<5, 1, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    if (g.samples == 1 && g.tile_log2 == 6) raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
+    else if (g.samples == 1 && g.tile_log2 == 5) raster_kernel<5, 1, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
     // (512 work-items, not 1024: at 1024 the kernel is capped at 128 registers and spills 500 bytes per work-item; measured 133 vs 386 us
     // on the reference's own 800x600 4-sample frame)
-    else if (g.samples == 4 && g.tile_log2 == 5) raster_kernel<5, 4, 512><<<grid, 512, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
-    else if (g.samples == 4 && g.tile_log2 == 4) raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, view0);
+    else if (g.samples == 4 && g.tile_log2 == 5) raster_kernel<5, 4, 512><<<grid, 512, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
+    else if (g.samples == 4 && g.tile_log2 == 4) raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
 }
 
 uint32_t setup_block_triangles() { return kSetupBlockTris; }

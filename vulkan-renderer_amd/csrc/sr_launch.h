@@ -44,17 +44,18 @@ bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, c
                              void* zero16, size_t zero_bytes);
 // triangle set-up (micro-triangles resolved, clip list and pending lists filled) followed by the binning of the pending lists
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
-                  const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, uint32_t view0,
+                  const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags /* of the target */, uint32_t view0,
                   hipEvent_t between /* recorded between set-up and binning, may be null */, bool bin = true /* false: set-up only */,
                   uint32_t fill_blocks = kFillBlocks);
 // near-plane clipping of the triangles set-up listed: cuts them and resolves the pieces into the visibility buffer.
 // Runs after launch_setup and before launch_scan (which reports the counters to the host).
 void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const float* px, const float* py, const float* pz,
-                      const ViewXform* views, const FrameGeom& g, const ClipList& clip, const BinBuffers& b, uint64_t* vis, uint32_t view0);
+                      const ViewXform* views, const FrameGeom& g, const ClipList& clip, const BinBuffers& b, uint64_t* vis, const BlockFlags& flags,
+                      uint32_t view0);
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters);
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views);
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
-                   uint64_t* vis, uint32_t view0, uint32_t n_views);
+                   uint64_t* vis, const BlockFlags& flags, uint32_t view0, uint32_t n_views);
 bool raster_config_supported(int samples, int tile_log2);
 uint32_t setup_block_triangles();   // triangles handled by one set-up block
 uint32_t chunk_triangles();         // triangles of one chunk of the pending list (what one turn of a binning workgroup takes)
