@@ -1007,17 +1007,19 @@ struct ShadeTables {
     const float* thresh;   // 255: linear value where the code steps from c to c+1
 };
 
-__device__ inline int srgb_encode8(float x, const float* thresh /* LDS or global, 255 entries */)
+// log2_x: log2(x), or anything near it -- it only seeds the search, the thresholds decide
+__device__ inline int srgb_encode8(float x, const float* thresh /* LDS or global, 255 entries */, float log2_x)
 {
     if (!(x > 0.0f)) return 0;
     if (x >= thresh[254]) return 255;
-    const float e = x <= 0.0031308f ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
+    const float e = x <= 0.0031308f ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(log2_x * (1.0f / 2.4f)) - 0.055f;
     int c = (int)(e * 255.0f + 0.5f);
     c = min(max(c, 0), 254);
     while (c < 254 && x >= thresh[c]) ++c;      // exact: smallest c with x < thresh[c]
     while (c > 0 && x < thresh[c - 1]) --c;
     return c;
 }
+__device__ inline int srgb_encode8(float x, const float* thresh) { return srgb_encode8(x, thresh, __builtin_amdgcn_logf(x)); }
 __device__ inline int unorm_encode8(float x)
 {
     if (!(x > 0.0f)) return 0;
@@ -1215,7 +1217,7 @@ __device__ inline float geometry_schlick_ggx(float NdotV, float roughness)
 
 // main() of shaders/shader.frag with the three texture() results passed in
 __device__ inline void fragment_main(const float* wp, const float* N, const float* cam, const float* albedo_tex,
-                                     float metallic, float roughness, float* out)
+                                     float metallic, float roughness, float* out, float* log2_out /* log2 of out */)
 {
     SR_COLOUR_MATH
     const float kPI = 3.14159265359f, kInvPI = 1.0f / 3.14159265359f;
@@ -1233,6 +1235,8 @@ __device__ inline void fragment_main(const float* wp, const float* N, const floa
     const float NdotV = max0(dot3(N, V));
     const float a = roughness * roughness, a2 = a * a;
     const float gv = geometry_schlick_ggx(NdotV, roughness);
+    const float rp1 = roughness + 1.0f, gk = (rp1 * rp1) * 0.125f;   // k of GeometrySchlickGGX
+    const float a2gv = a2 * gv;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float lp[3] = { (i & 1) ? 10.0f : -10.0f, (i & 2) ? -10.0f : 10.0f, 10.0f };
@@ -1246,16 +1250,15 @@ __device__ inline void fragment_main(const float* wp, const float* N, const floa
         const float attenuation = invd * invd;           // 1 / dot(D, D)
         const float NdotH = max0(dot3(N, Hv)), NdotH2 = NdotH * NdotH;
         float denom = fmaf(NdotH2, a2 - 1.0f, 1.0f);
-        denom = kPI * denom * denom;
-        const float NDF = a2 * frcp(denom);
+        denom = kPI * denom * denom;                      // NDF = a2 / denom
         const float NdotL = max0(dot3(N, L));
-        const float G = geometry_schlick_ggx(NdotL, roughness) * gv;
+        const float gl = fmaf(NdotL, 1.0f - gk, gk);      // G = NdotL / gl * gv
         const float x1 = 1.0f - max0(dot3(Hv, V));
         const float x2 = x1 * x1;
         const float fc = x2 * x2 * x1;                    // pow(x, 5.0)
         const float denominator = fmaf(4.0f * NdotV, NdotL, 0.001f);
-        const float rdn = frcp(denominator > 0.001f ? denominator : 0.001f);
-        const float ndg = NDF * G * rdn;
+        // NDF * G / max(denominator, 0.001) over one reciprocal of the three denominators' product (each lies between 1e-9 and 4)
+        const float ndg = (a2gv * NdotL) * frcp((denom * gl) * (denominator > 0.001f ? denominator : 0.001f));
         const float att_ndl = attenuation * NdotL;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -1269,7 +1272,8 @@ __device__ inline void fragment_main(const float* wp, const float* N, const floa
         const float ambient = 0.03f * albedo[c] * ao;
         float color = ambient + Lo[c];
         color = color * frcp(color + 1.0f);
-        out[c] = fast_pow(color, 1.0f / 2.2f);
+        log2_out[c] = __builtin_amdgcn_logf(color) * (1.0f / 2.2f);   // pow(color, 1.0 / 2.2)
+        out[c] = __builtin_amdgcn_exp2f(log2_out[c]);
     }
 }
 
@@ -1427,10 +1431,11 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
         if (p.paired) fetch_trilinear<1>(p.roughness.texels, tm, dec, rgh);    // the same for the whole launch
         else sample_texture<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
     }
-    fragment_main(wp, N, vx.cam, alb, met[0], rgh[0], rgb);
-    const uint32_t R = (uint32_t)srgb_encode8(rgb[0] > 1.0f ? 1.0f : rgb[0], thr);
-    const uint32_t G = (uint32_t)srgb_encode8(rgb[1] > 1.0f ? 1.0f : rgb[1], thr);
-    const uint32_t B = (uint32_t)srgb_encode8(rgb[2] > 1.0f ? 1.0f : rgb[2], thr);
+    float lg[3];
+    fragment_main(wp, N, vx.cam, alb, met[0], rgh[0], rgb, lg);
+    const uint32_t R = (uint32_t)srgb_encode8(rgb[0] > 1.0f ? 1.0f : rgb[0], thr, lg[0]);
+    const uint32_t G = (uint32_t)srgb_encode8(rgb[1] > 1.0f ? 1.0f : rgb[1], thr, lg[1]);
+    const uint32_t B = (uint32_t)srgb_encode8(rgb[2] > 1.0f ? 1.0f : rgb[2], thr, lg[2]);
     return B | (G << 8) | (R << 16) | (255u << 24);
     }
 }
