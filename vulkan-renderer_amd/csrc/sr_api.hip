@@ -175,7 +175,7 @@ int choose_tile_log2(const sr_device_t* dev, int samples)
 // per-view scratch bytes of a pass
 size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g)
 {
-    return (size_t)plane_stride(m->n_verts) * sizeof(ScreenVertex) + ((size_t)m->n_tris + 1024) * (4 * sizeof(BinRecord) + 4) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 16 + 64;
+    return (size_t)plane_stride(m->n_verts) * sizeof(ScreenVertex) + ((size_t)m->n_tris + 1024) * (4 * sizeof(BinRecord) + 4) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 16 + 64 + kPendingTotalStride * 4;
 }
 
 uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views)
@@ -212,7 +212,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     const size_t count_words = (size_t)vpp * n_tiles * 3;
     // layout of the binning state: [count_small | count_large | cursor_large | pending_total per view | counters of this pass |
     // spread micro-triangle counters] (zeroed at the start of every pass, padded to 16 bytes) [block_count: written by the binning kernel]
-    const size_t zero_words = (count_words + vpp + kNumPassCounters + kMicroSpread * kMicroSpreadStride + 3) & ~(size_t)3;
+    const size_t zero_words = (count_words + (size_t)vpp * kPendingTotalStride + kNumPassCounters + kMicroSpread * kMicroSpreadStride + 3) & ~(size_t)3;
     const size_t view_bytes = (size_t)n_views * sizeof(ViewXform);
     const uint32_t v_stride = std::max<uint32_t>(plane_stride(m->n_verts), 4);
     const size_t bytes_screen = (size_t)vpp * v_stride * sizeof(ScreenVertex);   // (12 of the 16 bytes are used: int2 plane, float plane)
@@ -292,7 +292,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     b.count_large = b.count_small + (size_t)vpp * n_tiles;
     b.cursor_large = b.count_large + (size_t)vpp * n_tiles;
     b.pending_total = b.count_small + count_words;
-    b.counters = b.pending_total + vpp;
+    b.counters = b.pending_total + (size_t)vpp * kPendingTotalStride;
     b.block_count = b.count_small + zero_words;
     b.micro_spread = b.counters + kNumPassCounters;
     b.pending = ps.pending;

@@ -224,6 +224,7 @@ enum : uint32_t {
     kCtrClipped = 8,       // triangles the near-plane clipper cut and drew
     kNumPassCounters = 16,
 };
+constexpr uint32_t kPendingTotalStride = 32;   // words between the pending-list lengths of two views
 constexpr uint32_t kMicroSpread = 64, kMicroSpreadStride = 64;   // counters, words between them (256 bytes)
 
 struct BinBuffers {
@@ -235,8 +236,10 @@ struct BinBuffers {
     uint32_t* refs;           // [capacity]: triangle ids grouped by (view, tile)
     uint32_t ref_capacity;
     uint32_t* pending;        // [views][pending_stride]: ids of the triangles set-up hands to the binning kernel, one list per view;
-                              // a set-up block reserves its place with one atomic add on pending_total
-    uint32_t* pending_total;  // [views], zeroed at the start of a pass
+                              // a wave of a set-up block reserves its place with one atomic add on the view's pending_total
+    uint32_t* pending_total;  // [views * kPendingTotalStride], zeroed at the start of a pass: length of the view's list, one counter per
+                              // 128 bytes (with the counters of 64 views side by side in four cache lines, the waves' atomic adds
+                              // queued up behind one another: set-up of a 64-view batch 21 -> 31 us)
     uint32_t pending_stride;  // >= triangles of the mesh
     BinRecord* records;       // [views][chunks][chunk triangles * kMaxSmallTiles]: the binning kernel takes the pending list in chunks,
                               // each chunk owns one segment
@@ -253,7 +256,7 @@ struct BinBuffers {
 // workgroup of the shading pass.
 struct PassReport {
     const uint32_t* counters;        // [kNumPassCounters]
-    const uint32_t* pending_total;   // [n_views]
+    const uint32_t* pending_total;   // [n_views * kPendingTotalStride]
     uint32_t n_views;
     const uint32_t* micro_spread;    // [kMicroSpread * kMicroSpreadStride]
     uint32_t* host_counters;         // null: nothing to report

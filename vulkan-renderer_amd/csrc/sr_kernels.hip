@@ -247,6 +247,9 @@ __device__ inline void micro_eval(const MicroEdges& e, int32_t px, int32_t py, i
 // Draws a micro-triangle: every sample of its box is tested with the edge functions, stepped incrementally (exact in integers) from
 // their value at the box's first pixel, and each covered sample goes into the visibility buffer with a 64-bit atomic min.  Depth is
 // the tile rasteriser's expression of the unbiased edge values.  Returns whether any sample was covered.
+// The box is walked as ONE loop over its npx * npy pixels, the step at the end of a row chosen by a select: lanes with boxes of
+// different shapes (1 x 4 beside 4 x 1) then take max(npx * npy) turns together instead of max(npx) * max(npy) -- set-up of the
+// 800 x 600 four-sample frame 15.2 -> 12.6 us, of the 64-view batch 21.3 -> 17.5 us, frames of sub-pixel triangles unchanged.
 template <int S>
 __device__ inline bool micro_draw(const MicroEdges& e, int x0, int y0, int npx, int npy, float z0, float z1, float z2, float rA,
                                   uint32_t tri, unsigned long long* vis_view, const FrameGeom& g)
@@ -255,26 +258,27 @@ __device__ inline bool micro_draw(const MicroEdges& e, int x0, int y0, int npx, 
     const int32_t sxa = -(e.cy - e.by) * kSubpix, sya = (e.cx - e.bx) * kSubpix;   // change per pixel step in x / y
     const int32_t sxb = -(e.ay - e.cy) * kSubpix, syb = (e.ax - e.cx) * kSubpix;
     const int32_t sxc = -(e.by - e.ay) * kSubpix, syc = (e.bx - e.ax) * kSubpix;
+    const int32_t wxa = sya - (npx - 1) * sxa, wxb = syb - (npx - 1) * sxb, wxc = syc - (npx - 1) * sxc;   // from the end of a row to the start of the next
+    const uint32_t step_row = (uint32_t)(g.rw - (npx - 1)) * S;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        int32_t Ra, Rb, Rc;
-        micro_eval(e, x0 * kSubpix + sample_dx(S, s), y0 * kSubpix + sample_dy(S, s), Ra, Rb, Rc);
-        Ra += e.bias_a; Rb += e.bias_b; Rc += e.bias_c;
-        unsigned long long* row = vis_view + ((size_t)(y0 - g.ry) * g.rw + (x0 - g.rx)) * S + s;
-        for (int j = 0; j < npy; ++j) {
-            int32_t Ea = Ra, Eb = Rb, Ec = Rc;
-            for (int i = 0; i < npx; ++i) {
-                if ((Ea | Eb | Ec) >= 0) {
-                    any = true;
-                    const float l0 = (float)(Ea - e.bias_a) * rA, l2 = (float)(Eb - e.bias_b) * rA, l1 = (float)(Ec - e.bias_c) * rA;
-                    float z = fmaf(l2, z2, fmaf(l1, z1, l0 * z0));
-                    z = z + 0.0f;
-                    if (z >= 0.0f && z < 1.0f) atomicMin(&row[(size_t)i * S], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
-                }
-                Ea += sxa; Eb += sxb; Ec += sxc;
+        int32_t Ea, Eb, Ec;
+        micro_eval(e, x0 * kSubpix + sample_dx(S, s), y0 * kSubpix + sample_dy(S, s), Ea, Eb, Ec);
+        Ea += e.bias_a; Eb += e.bias_b; Ec += e.bias_c;
+        unsigned long long* p = vis_view + ((size_t)(y0 - g.ry) * g.rw + (x0 - g.rx)) * S + s;
+        int i = 0;
+        for (int n = npx * npy; n > 0; --n) {
+            if ((Ea | Eb | Ec) >= 0) {
+                any = true;
+                const float l0 = (float)(Ea - e.bias_a) * rA, l2 = (float)(Eb - e.bias_b) * rA, l1 = (float)(Ec - e.bias_c) * rA;
+                float z = fmaf(l2, z2, fmaf(l1, z1, l0 * z0));
+                z = z + 0.0f;
+                if (z >= 0.0f && z < 1.0f) atomicMin(p, ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
             }
-            Ra += sya; Rb += syb; Rc += syc;
-            row += (size_t)g.rw * S;
+            const bool wrap = ++i == npx;
+            Ea += wrap ? wxa : sxa; Eb += wrap ? wxb : sxb; Ec += wrap ? wxc : sxc;
+            p += wrap ? step_row : (uint32_t)S;
+            i = wrap ? 0 : i;
         }
     }
     return any;
@@ -320,11 +324,13 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
                                                     FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, BlockFlags flags,
                                                     uint32_t view0, uint32_t n_views, uint32_t views_per_block)
 {
-    __shared__ uint32_t s_wave[kSetupTris * 4];
-    __shared__ uint32_t s_micro[4];
-    __shared__ uint32_t s_base;
-    __shared__ uint32_t s_q_tri[kSetupBlockTris], s_q_i0[kSetupBlockTris], s_q_i1[kSetupBlockTris], s_q_i2[kSetupBlockTris];
-    __shared__ uint32_t s_q_count;
+    // One barrier per view, between the two phases.  A wave that is through with a view goes on to the next while others still walk
+    // the queue, so the queue exists twice (views alternate) and its counter three times: the counter of the next view is zeroed at the
+    // top of a view, before the view's barrier -- its last readers finished two views ago and passed the previous barrier since, its
+    // next writers are behind this one.
+    constexpr uint32_t kQueues = VIEW_LOOP ? 2u : 1u;
+    __shared__ uint32_t s_q_tri[kQueues][kSetupBlockTris], s_q_i0[kQueues][kSetupBlockTris], s_q_i1[kQueues][kSetupBlockTris], s_q_i2[kQueues][kSetupBlockTris];
+    __shared__ uint32_t s_q_count[3];
     const uint32_t turn = xcd_runs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const uint32_t blk = turn % gridDim.x, view_begin = turn / gridDim.x * views_per_block;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
@@ -342,9 +348,11 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     // (VIEW_LOOP false = one view per workgroup: without the loop around it the code needs 63 registers instead of 90, which is worth
     // 5 % on a one-view frame of 10 M triangles)
     const uint32_t view_end = VIEW_LOOP ? min(view_begin + views_per_block, n_views) : view_begin + 1u;
-    for (uint32_t view = view_begin; view < view_end; ++view) {
-    if (tid == 0) s_q_count = 0u;
+    if (tid < 3u) s_q_count[tid] = 0u;
     __syncthreads();
+    for (uint32_t view = view_begin; view < view_end; ++view) {
+    const uint32_t turn_of_view = view - view_begin, qb = turn_of_view % kQueues, qc = turn_of_view % 3u;
+    if (VIEW_LOOP && tid == 0) s_q_count[(turn_of_view + 1u) % 3u] = 0u;
     const int2* xy = sp.xy + (size_t)view * sp.stride;
     int2 r0[kSetupTris], r1[kSetupTris], r2[kSetupTris];
 #pragma unroll
@@ -397,13 +405,13 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
 #pragma unroll
         for (uint32_t k = 0; k < kSetupTris; ++k) { qm[k] = __ballot(queued[k]); n += (uint32_t)__popcll(qm[k]); }
         uint32_t base = 0;
-        if (lane == 0 && n) base = atomicAdd(&s_q_count, n);
+        if (lane == 0 && n) base = atomicAdd(&s_q_count[qc], n);
         base = (uint32_t)__shfl((int)base, 0);
 #pragma unroll
         for (uint32_t k = 0; k < kSetupTris; ++k) {
             if (queued[k]) {
                 const uint32_t q = base + (uint32_t)__popcll(qm[k] & ((1ull << lane) - 1ull));
-                s_q_tri[q] = tri[k]; s_q_i0[q] = i0[k]; s_q_i1[q] = i1[k]; s_q_i2[q] = i2[k];
+                s_q_tri[qb][q] = tri[k]; s_q_i0[qb][q] = i0[k]; s_q_i1[qb][q] = i1[k]; s_q_i2[qb][q] = i2[k];
             }
             base += (uint32_t)__popcll(qm[k]);
         }
@@ -412,63 +420,52 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     {
         const float* zp = sp.z + (size_t)view * sp.stride;
         unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
-        const uint32_t n_q = s_q_count;
-        for (uint32_t q = tid; q < n_q; q += 256u) {
-            const uint32_t t = s_q_tri[q], j0 = s_q_i0[q], j1 = s_q_i1[q], j2 = s_q_i2[q];
-            const int2 a0 = xy[j0], a1 = xy[j1], a2 = xy[j2];
-            const float za = zp[j0], zb = zp[j1], zc = zp[j2];
-            int x0, y0, npx, npy;
-            sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
-            const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
-            if (micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_view, g)) {
-                ++n_micro;
-                // the blocks the box reaches into now hold something (one block as a rule, four at most: a box is smaller than a block)
-                const uint32_t bx0 = (uint32_t)(x0 - g.rx) / kFlagBlockW, bx1 = (uint32_t)(x0 + npx - 1 - g.rx) / kFlagBlockW;
-                const uint32_t by0 = (uint32_t)(y0 - g.ry) / kFlagBlockH, by1 = (uint32_t)(y0 + npy - 1 - g.ry) / kFlagBlockH;
-                flags.at(view0 + view, bx0, by0) = 1u;
-                if (bx1 != bx0) flags.at(view0 + view, bx1, by0) = 1u;
-                if (by1 != by0) { flags.at(view0 + view, bx0, by1) = 1u; if (bx1 != bx0) flags.at(view0 + view, bx1, by1) = 1u; }
+        const uint32_t n_q = s_q_count[qc];
+        for (uint32_t q0 = 0; q0 < n_q; q0 += 256u) {   // (the same number of turns for every work-item: the ballot below is reached by all)
+            const uint32_t q = q0 + tid;
+            bool drawn = false;
+            if (q < n_q) {
+                const uint32_t t = s_q_tri[qb][q], j0 = s_q_i0[qb][q], j1 = s_q_i1[qb][q], j2 = s_q_i2[qb][q];
+                const int2 a0 = xy[j0], a1 = xy[j1], a2 = xy[j2];
+                const float za = zp[j0], zb = zp[j1], zc = zp[j2];
+                int x0, y0, npx, npy;
+                sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
+                const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
+                drawn = micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_view, g);
+                if (drawn) {
+                    // the blocks the box reaches into now hold something (one block as a rule, four at most: a box is smaller than a block)
+                    const uint32_t bx0 = (uint32_t)(x0 - g.rx) / kFlagBlockW, bx1 = (uint32_t)(x0 + npx - 1 - g.rx) / kFlagBlockW;
+                    const uint32_t by0 = (uint32_t)(y0 - g.ry) / kFlagBlockH, by1 = (uint32_t)(y0 + npy - 1 - g.ry) / kFlagBlockH;
+                    flags.at(view0 + view, bx0, by0) = 1u;
+                    if (bx1 != bx0) flags.at(view0 + view, bx1, by0) = 1u;
+                    if (by1 != by0) { flags.at(view0 + view, bx0, by1) = 1u; if (bx1 != bx0) flags.at(view0 + view, bx1, by1) = 1u; }
+                }
             }
+            n_micro += (uint32_t)__popcll(__ballot(drawn));   // of the wave
         }
     }
     if (n_unproj) atomicAdd(&b.counters[kCtrUnprojectable], n_unproj);   // rare
-    // hand the remaining triangles to the binning kernel
+    // the count of micro-triangles drawn (instrumentation): one atomic per wave that drew any, spread over kMicroSpread counters a
+    // cache line apart (ten thousand atomic adds on ONE address cost the kernel 15 % of its time)
+    if (lane == 0 && n_micro) atomicAdd(&b.micro_spread[((blk * 4u + wave) % kMicroSpread) * kMicroSpreadStride], n_micro);
+    // hand the remaining triangles to the binning kernel: every wave that has any takes its own stretch of the view's pending list
+    // (ballots and prefix counts inside the wave, one atomic add)
     uint64_t m[kSetupTris];
+    uint32_t wave_total = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kSetupTris; ++k) {
-        m[k] = __ballot(pend[k]);
-        if (lane == 0) s_wave[k * 4u + wave] = (uint32_t)__popcll(m[k]);
-    }
-    {
-        uint32_t w = n_micro;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) w += (uint32_t)__shfl_down((int)w, o);
-        if (lane == 0) s_micro[wave] = w;
-    }
-    __syncthreads();
-    uint32_t total = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kSetupTris * 4u; ++k) total += s_wave[k];
-    if (tid == 0) {
-        // (spread over kMicroSpread counters a cache line apart: ten thousand atomic adds on ONE address cost the kernel 15 % of its time)
-        const uint32_t micro = s_micro[0] + s_micro[1] + s_micro[2] + s_micro[3];
-        if (micro) atomicAdd(&b.micro_spread[(blk % kMicroSpread) * kMicroSpreadStride], micro);
-        s_base = total ? atomicAdd(&b.pending_total[view], total) : 0u;
-    }
-    __syncthreads();
-    if (total != 0) {   // uniform over the block
-        uint32_t* list = b.pending + (size_t)view * b.pending_stride + s_base;
+    for (uint32_t k = 0; k < kSetupTris; ++k) { m[k] = __ballot(pend[k]); wave_total += (uint32_t)__popcll(m[k]); }
+    if (wave_total != 0) {   // uniform over the wave
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&b.pending_total[view * kPendingTotalStride], wave_total);
+        base = (uint32_t)__shfl((int)base, 0);
+        uint32_t* list = b.pending + (size_t)view * b.pending_stride + base;
         uint32_t run = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kSetupTris; ++k) {
-#pragma unroll
-            for (uint32_t w = 0; w < 4; ++w) {
-                if (w == wave && pend[k]) list[run + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))] = tri[k];
-                run += s_wave[k * 4u + w];
-            }
+            if (pend[k]) list[run + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))] = tri[k];
+            run += (uint32_t)__popcll(m[k]);
         }
     }
-    __syncthreads();   // the workgroup's tables are free for the next view
     }
 }
 
@@ -489,7 +486,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
     const uint32_t lane = lane_id();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
-    const uint32_t n_pending = min(b.pending_total[view], b.pending_stride);
+    const uint32_t n_pending = min(b.pending_total[view * kPendingTotalStride], b.pending_stride);
     const uint32_t n_chunks = (n_pending + kBlockTris - 1u) / kBlockTris;
     uint32_t span_chunks = 1u;
     while (span_chunks < n_chunks) span_chunks <<= 1;
@@ -701,7 +698,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
         // results of the pass for the host, written straight into pinned host memory (read after the
         // stream has been synchronised): total references, -, unprojectable, binned, direct, -, clipped
         uint32_t binned = 0;
-        for (uint32_t v = 0; v < n_views; ++v) binned += pending_total[v];
+        for (uint32_t v = 0; v < n_views; ++v) binned += pending_total[v * kPendingTotalStride];
         host_counters[0] = carry; host_counters[1] = 0u; host_counters[2] = counters[kCtrUnprojectable];
         host_counters[3] = binned; host_counters[4] = s_micro_total; host_counters[5] = counters[kCtrClipListed];
         host_counters[6] = counters[kCtrClipped];
@@ -720,7 +717,7 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameGeom g, BinBuffers b)
     const uint32_t* offset = b.tile_offset + (size_t)view * n_tiles;
     const uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
     uint32_t* cursor_large = b.cursor_large + (size_t)view * n_tiles;
-    const uint32_t n_chunks = (min(b.pending_total[view], b.pending_stride) + kBlockTris - 1u) / kBlockTris;
+    const uint32_t n_chunks = (min(b.pending_total[view * kPendingTotalStride], b.pending_stride) + kBlockTris - 1u) / kBlockTris;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint32_t n = min(b.block_count[(size_t)view * b.n_blocks + chunk], kBlockRecords);
         const BinRecord* seg = b.records + ((size_t)view * b.n_blocks + chunk) * kBlockRecords;
@@ -1453,7 +1450,7 @@ __device__ inline void report_pass(const PassReport& r, uint32_t lane)
     for (int o = 32; o > 0; o >>= 1) micro += (uint32_t)__shfl_down((int)micro, o);
     if (lane == 0) {
         uint32_t binned = 0;
-        for (uint32_t v = 0; v < r.n_views; ++v) binned += r.pending_total[v];
+        for (uint32_t v = 0; v < r.n_views; ++v) binned += r.pending_total[v * kPendingTotalStride];
         uint32_t* h = r.host_counters;
         h[0] = 0u; h[1] = 0u; h[2] = r.counters[kCtrUnprojectable]; h[3] = binned; h[4] = micro;
         h[5] = r.counters[kCtrClipListed]; h[6] = r.counters[kCtrClipped];
