@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Copies the summaries of gpurun_out/profile_round into profiles/ (tracked) and derives traffic.json:
 HBM bytes per launch of each kernel = (2 * FETCH_SIZE + WRITE_SIZE) KiB, the factor 2 being the gfx950
-correction for FETCH_SIZE (it reports half the bytes of a coalesced read; checked here on the vertex
-kernel, whose read volume is known exactly: 12 bytes per vertex)."""
+correction for FETCH_SIZE (it tallies every 128-byte line at 64 bytes, for streaming reads and for gathers alike:
+tools/ubench/gather.hip; cross-checked on the vertex kernel, whose read volume is known exactly: 12 bytes per vertex)."""
 import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -40,8 +40,8 @@ for k, short in names.items():
 # the digest ties the figures to the kernel sources they were measured on: bench.py prints `traffic` only when it matches
 json.dump({"kernel_source_digest": bench.kernel_source_digest(), "c3_4k_10Mtri": traffic}, open("profiles/traffic.json", "w"), indent=1)
 json.dump({"workload": "c3_4k_10Mtri", "kernel_source_digest": bench.kernel_source_digest(),
-           "note": "per launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.  The factor 2 is calibrated for wide coalesced reads "
-                   "(vertex kernel); for the gather-heavy set-up and fragment kernels the true read volume lies between FETCH_SIZE and 2*FETCH_SIZE",
+           "note": "per launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.  FETCH_SIZE tallies every 128-byte line at 64 bytes, for "
+                   "streaming reads and for gathers alike (profiles/r2_fetch_size_calibration.json), hence the factor 2",
            "kernels": detail},
           open(f"profiles/{tag}_c3_hbm_traffic.json", "w"), indent=1)
 print(open(f"profiles/{tag}_c3_kernel_stats.csv").read()[:1800])
