@@ -372,6 +372,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(workload, dom), "algorithmic_bytes": int(by[dom]),
                          "kernel_source_digest": kernel_source_digest()},
         }
+        if world > 1:
+            # the default one-GPU line is the 4K headline frame, a different workload: the one-GPU point of THIS series is
+            # `python bench.py --workload <this workload>`, and with no collective on the data path every rank's own rate
+            # (per_gpu_Mtris_per_s) is what it measures
+            out["scaling_note"] = (f"weak scaling by view, no collective: the N=1 point of this series is `python bench.py --workload {workload}` "
+                                   "(each entry of per_gpu_Mtris_per_s is one GPU's rate on its share); the default N=1 line is the c3_4k_10Mtri headline, another workload")
         if world == 1 and args.max_anisotropy <= 1.0:
             # the same frame through the sampler the reference creates (maxAnisotropy 16): a second figure, not the headline
             tex16 = [sr.create_texture(dev, im, sampler=sr.default_sampler(16.0)) if im is not None else None for im in images]

@@ -99,6 +99,7 @@ SR_API const char* sr_last_error_string(void);
  * vertices: n_vertices records of the reference's Vertex (32 bytes: pos f32x3, normal f32x3,
  * uv f32x2; src/mesh.hpp:18-54).  indices: uint32 triangle list (src/main.cpp:561, 947-948).
  * Data is fully uploaded on return, as with the reference's blocking staging copies.
+ * At most 2^29 - 4 vertices (SR_ERR_UNSUPPORTED beyond; 17 GB of vertex records).
  * A mesh (and a texture) may be destroyed at any time after the draws that use it were issued: sr_mesh_destroy and
  * sr_texture_destroy first complete those draws, as the reference waits for the device to be idle before it
  * destroys its buffers (src/main.cpp:170, 300-347). */

@@ -5,6 +5,8 @@ must be bit-exact, colour within 1 LSB on 99.9 % of the pixels (on frames with e
 the percentage to mean something).
 
     python tests/emu/fuzz_parity.py [first_seed [count]]        SR_FUZZ_ANISOTROPIC=1: samplers with maxAnisotropy 16 on both sides
+                                                                SR_FUZZ_GPU=1: the shipped library on GPU 0 instead of the CPU execution
+                                                                of the kernel sources (same cases, same checks; a GPU box only)
 """
 import os
 import sys
@@ -111,11 +113,13 @@ def check_seed(seed, sr, oracle, dev, util, vertex_stage_too=False):
 
 
 def main():
-    import build_emu
     import softraster as sr
     import util
     from oracle import oracle
-    sr.LIB_PATH = build_emu.build()
+    on_gpu = os.environ.get("SR_FUZZ_GPU") == "1"
+    if not on_gpu:
+        import build_emu
+        sr.LIB_PATH = build_emu.build()
     aniso = os.environ.get("SR_FUZZ_ANISOTROPIC") == "1"
     sr.DEFAULT_MAX_ANISOTROPY = 16.0 if aniso else 1.0
     oracle.set_anisotropic(aniso)
@@ -129,7 +133,9 @@ def main():
         lowest, clipped, dropped = check_seed(seed, sr, oracle, dev, util, vertex_stage_too=seed % 4 == 0)
         worst_frac = min(worst_frac, lowest)
         total_clipped += clipped; total_dropped += dropped
-    print(f"ok: seeds {first}..{first + count - 1}, lowest colour fraction on well-covered frames {worst_frac:.5f}"
+        if on_gpu and (seed - first) % 200 == 199:
+            print(f"... through seed {seed}, lowest colour fraction so far {worst_frac:.5f}", flush=True)
+    print(f"ok: seeds {first}..{first + count - 1} on {'the GPU' if on_gpu else 'the CPU execution of the kernels'}, lowest colour fraction on well-covered frames {worst_frac:.5f}"
           f"; near-plane clipper: {total_clipped} triangles clipped, {total_dropped} given up")
 
 

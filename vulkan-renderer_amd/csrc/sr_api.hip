@@ -509,6 +509,8 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
     if (!dev || !out) return fail(SR_ERR_INVALID_ARGUMENT, "device or out is NULL");
     *out = nullptr;
     if ((n_vertices && !vertices) || (n_indices && !indices)) return fail(SR_ERR_INVALID_ARGUMENT, "NULL data with a non-zero count");
+    // (the set-up kernel addresses a view's window-space planes with 32-bit byte offsets, 8 bytes per vertex)
+    if (n_vertices > (1u << 29) - 4u) return fail(SR_ERR_UNSUPPORTED, "a mesh holds at most 2^29 - 4 vertices");
     const uint32_t n_tris = n_indices / 3;   // an incomplete trailing primitive is not drawn
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (indices[i] >= n_vertices) return fail(SR_ERR_INDEX_OUT_OF_RANGE, "index " + std::to_string(i) + " = " + std::to_string(indices[i]) + " >= " + std::to_string(n_vertices));

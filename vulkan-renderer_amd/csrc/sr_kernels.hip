@@ -313,6 +313,22 @@ __device__ inline uint32_t xcd_runs(uint32_t b, uint32_t n)
     return ((j / kXcdRun) * 8u + x) * kXcdRun + j % kXcdRun;
 }
 
+// SR_IN_LOOP(x): x, a 32-bit byte offset that does not change from view to view, is declared opaque at the place of its use.  Without
+// it the compiler widens the offsets to 64 bits once, before the view loop, and adds the view's plane base to each with a 64-bit
+// vector addition per gather and view (nine register pairs, nine additions); with it every gather is `base in scalar registers + 32-bit
+// offset` (the view-loop kernel: 84 -> 65 registers).  Emits no instruction.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SR_IN_LOOP(x) asm volatile("" : "+v"(x))
+#else
+#define SR_IN_LOOP(x) ((void)0)
+#endif
+// element of a per-view plane at a 32-bit byte offset from the plane's base (the base is the same for the whole wave)
+template <class T>
+__device__ inline T plane_at(const T* plane, uint32_t byte_offset)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(plane) + byte_offset);
+}
+
 // Set-up: one lane handles kSetupTris triangles (all index loads first, then all vertex loads, so
 // nine independent gathers are in flight per lane).  Back faces, degenerate triangles and boxes
 // that contain no sample point are dropped; micro-triangles are resolved here, in a second phase; triangles with
@@ -334,6 +350,9 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     const uint32_t turn = xcd_runs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const uint32_t blk = turn % gridDim.x, view_begin = turn / gridDim.x * views_per_block;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    // i0, i1, i2: the three vertices of a triangle as BYTE offsets into a view's xy plane (index * 8; half of it is the offset into the
+    // z plane).  A plane holds fewer than 2^29 vertices (checked when the mesh is made), so the offsets fit 32 bits and every gather is
+    // a plane's base address, the same for the whole wave, plus a 32-bit offset per lane: no 64-bit address arithmetic per view.
     uint32_t tri[kSetupTris], i0[kSetupTris], i1[kSetupTris], i2[kSetupTris];
     bool in_range[kSetupTris];
 #pragma unroll
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
         tri[k] = blk * kSetupBlockTris + k * 256u + tid;
         in_range[k] = tri[k] < n_tris;
         const uint32_t tt = in_range[k] ? tri[k] : 0u;
-        i0[k] = idx[3 * (size_t)tt]; i1[k] = idx[3 * (size_t)tt + 1]; i2[k] = idx[3 * (size_t)tt + 2];
+        i0[k] = idx[3 * (size_t)tt] << 3; i1[k] = idx[3 * (size_t)tt + 1] << 3; i2[k] = idx[3 * (size_t)tt + 2] << 3;
     }
     // the indices are loaded once for all the views the workgroup handles (every view of a pass, unless the mesh is small): a batch of
     // views streams the index list once instead of once per view
@@ -356,18 +375,41 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     const int2* xy = sp.xy + (size_t)view * sp.stride;
     int2 r0[kSetupTris], r1[kSetupTris], r2[kSetupTris];
 #pragma unroll
-    for (uint32_t k = 0; k < kSetupTris; ++k) { r0[k] = xy[i0[k]]; r1[k] = xy[i1[k]]; r2[k] = xy[i2[k]]; }
+    for (uint32_t k = 0; k < kSetupTris; ++k) {
+        SR_IN_LOOP(i0[k]); SR_IN_LOOP(i1[k]); SR_IN_LOOP(i2[k]);
+        r0[k] = plane_at(xy, i0[k]); r1[k] = plane_at(xy, i1[k]); r2[k] = plane_at(xy, i2[k]);
+    }
 
     // Phase one: the cheap tests, for every triangle.  Micro-triangles whose box holds a sample point are queued in LDS (their id and
-    // their three indices); phase two takes them one per work-item, every lane busy, fetches positions and depths (cache hits: the
+    // their three vertex offsets); phase two takes them one per work-item, every lane busy, fetches positions and depths (cache hits: the
     // workgroup touched those lines a moment ago), walks the few samples and does the atomic mins.  Run in place, at the one lane in
     // three or ten that holds such a triangle, the sample walk was most of the kernel's instructions.
     uint32_t n_unproj = 0, n_micro = 0;
     bool pend[kSetupTris], queued[kSetupTris];
+    // a vertex that cannot be projected has x = INT32_MIN, which then is the smallest x of its triangle.  Triangles with one or two
+    // such vertices need the near-plane clipper (a full list drops and counts the triangle): rare, one test for all the wave's triangles
+    int mnx_of[kSetupTris];
+    bool bad_any = false;
+#pragma unroll
+    for (uint32_t k = 0; k < kSetupTris; ++k) {
+        mnx_of[k] = min(r0[k].x, min(r1[k].x, r2[k].x));
+        bad_any |= (mnx_of[k] == kBadVertexX) & in_range[k];   // (no short circuit: branch-free)
+    }
+    if (__ballot(bad_any) != 0ull) {
+#pragma unroll
+        for (uint32_t k = 0; k < kSetupTris; ++k) {
+            const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
+            if (in_range[k] && bad > 0 && bad < 3) {
+                const uint32_t slot = atomicAdd(&b.counters[kCtrClipListed], 1u);
+                if (slot < clip.capacity) clip.entries[slot] = make_uint2(view, tri[k]);
+                else ++n_unproj;
+            }
+        }
+    }
 #pragma unroll
     for (uint32_t k = 0; k < kSetupTris; ++k) {
         pend[k] = false; queued[k] = false;
-        const int mnx = min(r0[k].x, min(r1[k].x, r2[k].x)), mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
+        const int mnx = mnx_of[k], mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
         const int mny = min(r0[k].y, min(r1[k].y, r2[k].y)), mxy = max(r0[k].y, max(r1[k].y, r2[k].y));
         // facing: the sign of the doubled area.  A box under 64 pixels on both axes (differences in unsigned arithmetic: x is INT32_MIN
         // for a vertex that cannot be projected) keeps every factor below 2^15: the 24-bit multiplier is exact and the products fit 32
@@ -380,17 +422,7 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             if (!small_box) front = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
                                     (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y) < 0;
         }
-        // a vertex that cannot be projected has x = INT32_MIN, which then is the smallest x of the triangle
         const bool any_bad = mnx == kBadVertexX;
-        if (__ballot(any_bad && in_range[k]) != 0ull) {   // rare
-            const int bad = (r0[k].x == kBadVertexX) + (r1[k].x == kBadVertexX) + (r2[k].x == kBadVertexX);
-            if (in_range[k] && bad > 0 && bad < 3) {
-                // needs the near-plane clipper; a full list drops and counts the triangle
-                const uint32_t slot = atomicAdd(&b.counters[kCtrClipListed], 1u);
-                if (slot < clip.capacity) clip.entries[slot] = make_uint2(view, tri[k]);
-                else ++n_unproj;
-            }
-        }
         if (in_range[k] && !any_bad && front) {
             int x0, y0, npx, npy;
             if (sample_box<S>(mnx, mxx, mny, mxy, g, x0, y0, npx, npy)) {
@@ -426,8 +458,8 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             bool drawn = false;
             if (q < n_q) {
                 const uint32_t t = s_q_tri[qb][q], j0 = s_q_i0[qb][q], j1 = s_q_i1[qb][q], j2 = s_q_i2[qb][q];
-                const int2 a0 = xy[j0], a1 = xy[j1], a2 = xy[j2];
-                const float za = zp[j0], zb = zp[j1], zc = zp[j2];
+                const int2 a0 = plane_at(xy, j0), a1 = plane_at(xy, j1), a2 = plane_at(xy, j2);
+                const float za = plane_at(zp, j0 >> 1), zb = plane_at(zp, j1 >> 1), zc = plane_at(zp, j2 >> 1);
                 int x0, y0, npx, npy;
                 sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
                 const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
