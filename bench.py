@@ -60,13 +60,13 @@ def kernel_bytes(st, n_tiles):
     views, passes = max(st.get("views", 1), 1), max(st.get("passes", 1), 1)
     per_pass = -(-views // passes)
 
-    def reads_per_view(units_per_view, block_units, fused=False):
+    def reads_per_view(units_per_view, block_units, fused=False, cap=None):
         """How often, per view, a kernel whose workgroups take several views of a pass reads the mesh (the launchers' rule: all views
-        of the pass per workgroup unless that leaves fewer than 4096 workgroups)."""
+        of the pass per workgroup unless that leaves fewer than 4096 workgroups; the batch vertex kernel takes at most 8)."""
         grid_x = -(-units_per_view // block_units)
-        per_block = per_pass if fused else min(max(per_pass * grid_x // 4096, 1), per_pass)
+        per_block = per_pass if fused else min(max(per_pass * grid_x // 4096, 1), per_pass, cap or per_pass)
         return passes * -(-per_pass // per_block) / views
-    vertex_reads = reads_per_view(V // views, 512, fused=views <= 8)
+    vertex_reads = reads_per_view(V // views, 512, fused=views <= 8, cap=8)
     index_reads = reads_per_view(T // views, 768)
     return {
         "clear": P * S * 8,                                                   # visibility words written (only the covered blocks are; counted in full)

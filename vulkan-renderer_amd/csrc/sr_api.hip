@@ -172,15 +172,20 @@ int choose_tile_log2(const sr_device_t* dev, int samples)
     return samples == 1 ? 6 : 5;
 }
 
-// per-view scratch bytes of a pass
-size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g)
+// bytes per vertex and view of the window-space planes of a pass: int2 xy, float z
+constexpr size_t kPlaneBytesPerVertex = sizeof(int2) + sizeof(float);
+
+// per-view scratch bytes of a pass.  A lean draw launches no binning kernel and so needs no binning records, by far the largest
+// buffer (48 of 64 bytes per triangle): its passes take several times as many views, and a pass reads the mesh once.
+size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g, bool lean)
 {
-    return (size_t)plane_stride(m->n_verts) * sizeof(ScreenVertex) + ((size_t)m->n_tris + 1024) * (4 * sizeof(BinRecord) + 4) + (size_t)m->n_tris / 64 + (size_t)g.tiles_x * g.tiles_y * 16 + 64 + kPendingTotalStride * 4;
+    return (size_t)plane_stride(m->n_verts) * kPlaneBytesPerVertex + ((size_t)m->n_tris + 1024) * ((lean ? 0 : 4 * sizeof(BinRecord)) + 4) + (size_t)m->n_tris / 64 +
+           (size_t)g.tiles_x * g.tiles_y * 16 + 64 + kPendingTotalStride * 4;
 }
 
-uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views)
+uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views, bool lean)
 {
-    size_t pv = per_view_bytes(m, g);
+    size_t pv = per_view_bytes(m, g, lean);
     uint64_t by_mem = std::max<uint64_t>(1, dev->scratch_budget / std::max<size_t>(pv, 1));
     uint64_t by_refs = std::max<uint64_t>(1, (uint64_t)0x7FFFFFFF / std::max<uint32_t>(m->n_tris, 1));
     uint64_t v = std::min<uint64_t>({(uint64_t)n_views, by_mem, by_refs, (uint64_t)65535});
@@ -201,7 +206,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     const FrameGeom& g = tg->g;
     const uint32_t n_views = (uint32_t)tg->views.size();
     const bool no_alloc = tg->no_alloc;
-    const uint32_t vpp = no_alloc ? n_views : views_per_pass(dev, m, g, n_views);
+    const uint32_t vpp = no_alloc ? n_views : views_per_pass(dev, m, g, n_views, tg->lean);
     const uint32_t passes = (n_views + vpp - 1) / vpp;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
     hipStream_t st = dev->stream;
@@ -215,11 +220,11 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     const size_t zero_words = (count_words + (size_t)vpp * kPendingTotalStride + kNumPassCounters + kMicroSpread * kMicroSpreadStride + 3) & ~(size_t)3;
     const size_t view_bytes = (size_t)n_views * sizeof(ViewXform);
     const uint32_t v_stride = std::max<uint32_t>(plane_stride(m->n_verts), 4);
-    const size_t bytes_screen = (size_t)vpp * v_stride * sizeof(ScreenVertex);   // (12 of the 16 bytes are used: int2 plane, float plane)
+    const size_t bytes_screen = (size_t)vpp * v_stride * kPlaneBytesPerVertex;   // the int2 plane of every view of the pass, then the float plane
     const size_t bytes_tile_count = (zero_words + (size_t)vpp * n_blocks) * 4;
     const size_t bytes_pending = (size_t)vpp * pending_stride * 4;
     const size_t bytes_tile_offset = ((size_t)vpp * n_tiles + 1) * 4;
-    const size_t bytes_records = (size_t)vpp * n_blocks * setup_block_records() * sizeof(BinRecord);
+    const size_t bytes_records = tg->lean && !no_alloc ? 0 : (size_t)vpp * n_blocks * setup_block_records() * sizeof(BinRecord);   // (a lean draw has no binning kernel)
     PassScratch ps;
     sr_device_t::Staging* staging = nullptr;
     if (no_alloc) {

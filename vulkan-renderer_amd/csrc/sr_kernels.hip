@@ -98,6 +98,10 @@ __global__ __launch_bounds__(64) void store_views_kernel(ViewPack pack, uint32_t
 // 5 M vertices), G = 2 for the view batch.
 // =================================================================================================
 constexpr uint32_t kFusedVertexGroup = 4, kBatchVertexGroup = 2;
+#ifndef SR_VERTEX_VIEWS
+#define SR_VERTEX_VIEWS 8
+#endif
+constexpr uint32_t kVertexViewsPerBlock = SR_VERTEX_VIEWS;   // views a workgroup of the batch vertex kernel goes through with its positions loaded once
 template <uint32_t G> struct VecOf;
 template <> struct VecOf<1> { typedef float F; typedef int2 I; };
 template <> struct VecOf<2> { typedef float2 F; typedef int4 I; };
@@ -1711,9 +1715,13 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
                    int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out, uint32_t fill_blocks)
 {
     if (!n || !n_views) return;
-    // a workgroup takes every view of the launch for its vertices, unless the mesh is too small to fill the chip that way
+    // a workgroup takes up to kVertexViewsPerBlock views of the launch for its vertices (fewer if the mesh is too small to fill the
+    // chip that way).  Not all of a long pass: every view adds two output streams (xy and z plane) per workgroup, and with several
+    // dozen streams per workgroup the stores lose more in the memory system than reading the positions once more costs (the
+    // 50 M-triangle batch, 34 views per pass: every view per workgroup 11.2 ms, sixteen 11.0 ms, eight 10.0 ms, four 9.9 ms).
     const uint32_t grid_x = div_up(n, kBatchVertexGroup * 256u);
-    const uint32_t views_per_block = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views);
+    uint32_t views_per_block = std::min<uint32_t>({std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views, kVertexViewsPerBlock});
+    views_per_block = div_up(n_views, div_up(n_views, views_per_block));   // the same number of rows of workgroups, evenly filled (17 views: 6 + 6 + 5, not 8 + 8 + 1)
     vertex_kernel<<<dim3(grid_x, div_up(n_views, views_per_block)), 256, 0, st>>>(px, py, pz, n, views, n_views, views_per_block, W, H, out, debug_out,
                                                                                    (float4*)clip_out);
 }
