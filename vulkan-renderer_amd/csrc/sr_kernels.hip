@@ -301,6 +301,24 @@ __device__ inline bool sample_box(int mnx, int mxx, int mny, int mxy, const Fram
     return npx > 0 && npy > 0;
 }
 
+// The same with the spans computed in unsigned arithmetic (which wraps): for callers that evaluate it unconditionally, also on the
+// INT32_MIN coordinates of vertices that cannot be projected, and discard the answer for those.
+template <int S>
+__device__ inline bool sample_box_wrapping(int mnx, int mxx, int mny, int mxy, const FrameGeom& g, int& x0, int& y0, int& npx, int& npy)
+{
+    int x1, y1;
+    if (S == 1) {
+        x0 = (int32_t)((uint32_t)mnx + (uint32_t)(kSubpix - 1 - kHalf)) >> 8; x1 = (int32_t)((uint32_t)mxx - (uint32_t)kHalf) >> 8;
+        y0 = (int32_t)((uint32_t)mny + (uint32_t)(kSubpix - 1 - kHalf)) >> 8; y1 = (int32_t)((uint32_t)mxy - (uint32_t)kHalf) >> 8;
+    } else {
+        x0 = mnx >> 8; x1 = mxx >> 8; y0 = mny >> 8; y1 = mxy >> 8;
+    }
+    x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+    y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+    npx = (int32_t)((uint32_t)x1 - (uint32_t)x0 + 1u); npy = (int32_t)((uint32_t)y1 - (uint32_t)y0 + 1u);
+    return (npx > 0) & (npy > 0);
+}
+
 // The hardware deals workgroups to the eight XCDs round robin by linear workgroup id, and every XCD has an L2 of its own.  Neighbouring
 // parts of a mesh share vertices and land on neighbouring pixels, so with the plain order every vertex line is fetched by several
 // L2s and the lines of the visibility buffer travel between them under the atomic mins.  xcd_runs renumbers the workgroups so that
@@ -410,30 +428,39 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             }
         }
     }
+    // facing: the sign of the doubled area.  A box under 64 pixels on both axes (differences in unsigned arithmetic: x is INT32_MIN
+    // for a vertex that cannot be projected) keeps every factor below 2^15: the 24-bit multiplier is exact and the products fit 32
+    // bits; else 64 bits -- a path the wave skips, for its three triangles at once, unless one of them needs it.
+    int mxx_of[kSetupTris], mny_of[kSetupTris], mxy_of[kSetupTris];
+    bool small_box[kSetupTris], front[kSetupTris];
+    bool big_any = false;
 #pragma unroll
     for (uint32_t k = 0; k < kSetupTris; ++k) {
-        pend[k] = false; queued[k] = false;
-        const int mnx = mnx_of[k], mxx = max(r0[k].x, max(r1[k].x, r2[k].x));
-        const int mny = min(r0[k].y, min(r1[k].y, r2[k].y)), mxy = max(r0[k].y, max(r1[k].y, r2[k].y));
-        // facing: the sign of the doubled area.  A box under 64 pixels on both axes (differences in unsigned arithmetic: x is INT32_MIN
-        // for a vertex that cannot be projected) keeps every factor below 2^15: the 24-bit multiplier is exact and the products fit 32
-        // bits; else 64 bits -- a path the wave skips unless one of its triangles needs it.
-        const bool small_box = (uint32_t)mxx - (uint32_t)mnx < 16384u && (uint32_t)mxy - (uint32_t)mny < 16384u;
+        mxx_of[k] = max(r0[k].x, max(r1[k].x, r2[k].x));
+        mny_of[k] = min(r0[k].y, min(r1[k].y, r2[k].y)); mxy_of[k] = max(r0[k].y, max(r1[k].y, r2[k].y));
+        small_box[k] = (((uint32_t)mxx_of[k] - (uint32_t)mnx_of[k]) | ((uint32_t)mxy_of[k] - (uint32_t)mny_of[k])) < 16384u;
         // (differences in unsigned arithmetic, which wraps: for a larger box the 32-bit value means nothing and is replaced below)
-        bool front = (int32_t)((uint32_t)__mul24((int)((uint32_t)r1[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r2[k].y - (uint32_t)r0[k].y)) -
-                               (uint32_t)__mul24((int)((uint32_t)r2[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r1[k].y - (uint32_t)r0[k].y))) < 0;
-        if (__ballot(!small_box) != 0ull) {
-            if (!small_box) front = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
-                                    (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y) < 0;
-        }
-        const bool any_bad = mnx == kBadVertexX;
-        if (in_range[k] && !any_bad && front) {
-            int x0, y0, npx, npy;
-            if (sample_box<S>(mnx, mxx, mny, mxy, g, x0, y0, npx, npy)) {
-                if (__mul24(npx, npy) <= micro_pixels<S>() && small_box) queued[k] = true;   // (npx, npy <= 16384)
-                else pend[k] = true;
-            }
-        }
+        front[k] = (int32_t)((uint32_t)__mul24((int)((uint32_t)r1[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r2[k].y - (uint32_t)r0[k].y)) -
+                             (uint32_t)__mul24((int)((uint32_t)r2[k].x - (uint32_t)r0[k].x), (int)((uint32_t)r1[k].y - (uint32_t)r0[k].y))) < 0;
+        big_any |= !small_box[k];
+    }
+    if (__ballot(big_any) != 0ull) {
+#pragma unroll
+        for (uint32_t k = 0; k < kSetupTris; ++k)
+            if (!small_box[k]) front[k] = (int64_t)(int32_t)((uint32_t)r1[k].x - (uint32_t)r0[k].x) * (int64_t)(r2[k].y - r0[k].y) -
+                                          (int64_t)(int32_t)((uint32_t)r2[k].x - (uint32_t)r0[k].x) * (int64_t)(r1[k].y - r0[k].y) < 0;
+    }
+    // No branches from here on (the kernel is bound by the instructions it issues, scalar ones included, and every nested
+    // condition costs a wave several of those whether or not it skips anything): the sample box is worked out for every
+    // triangle, in arithmetic that wraps for the coordinates of unprojectable vertices, and the conditions are combined.
+#pragma unroll
+    for (uint32_t k = 0; k < kSetupTris; ++k) {
+        const bool candidate = in_range[k] & (mnx_of[k] != kBadVertexX) & front[k];
+        int x0, y0, npx, npy;
+        const bool holds_sample = sample_box_wrapping<S>(mnx_of[k], mxx_of[k], mny_of[k], mxy_of[k], g, x0, y0, npx, npy);
+        const bool micro = (__mul24(npx, npy) <= micro_pixels<S>()) & small_box[k];   // (npx, npy <= 16384 where it counts)
+        queued[k] = candidate & holds_sample & micro;
+        pend[k] = candidate & holds_sample & !micro;
     }
     {   // the wave's queued triangles take their places in the workgroup's queue: one LDS atomic per wave
         uint64_t qm[kSetupTris];
@@ -1722,8 +1749,18 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
     const uint32_t grid_x = div_up(n, kBatchVertexGroup * 256u);
     uint32_t views_per_block = std::min<uint32_t>({std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views, kVertexViewsPerBlock});
     views_per_block = div_up(n_views, div_up(n_views, views_per_block));   // the same number of rows of workgroups, evenly filled (17 views: 6 + 6 + 5, not 8 + 8 + 1)
-    vertex_kernel<<<dim3(grid_x, div_up(n_views, views_per_block)), 256, 0, st>>>(px, py, pz, n, views, n_views, views_per_block, W, H, out, debug_out,
-                                                                                   (float4*)clip_out);
+    if (grid_x < std::max(fill_blocks, 1u)) {   // a small mesh: one launch, a row of workgroups per group of views
+        vertex_kernel<<<dim3(grid_x, div_up(n_views, views_per_block)), 256, 0, st>>>(px, py, pz, n, views, n_views, views_per_block, W, H, out, debug_out,
+                                                                                       (float4*)clip_out);
+        return;
+    }
+    // a large one: one launch per row (rows of one launch run into each other, which costs the 50 M-triangle batch 4 % of this kernel)
+    for (uint32_t v = 0; v < n_views; v += views_per_block) {
+        ScreenPlanes o = out; o.xy += (size_t)v * out.stride; o.z += (size_t)v * out.stride;
+        const uint32_t nv = std::min(views_per_block, n_views - v);
+        vertex_kernel<<<dim3(grid_x, 1), 256, 0, st>>>(px, py, pz, n, views + v, nv, nv, W, H, o, debug_out ? debug_out + (size_t)v * n : nullptr,
+                                                       clip_out ? (float4*)clip_out + (size_t)v * n : nullptr);
+    }
 }
 
 // workgroups of the kernels that walk the pending list in chunks: enough to fill the chip when the list is long, few
