@@ -189,7 +189,7 @@ def sort_first(args, sr, rank, local_rank, world):
     probe.destroy()
     if world > 1:
         dist.all_reduce(rows)
-    bands = d.balance_bands(W / 8 + rows.cpu().numpy(), W, world)
+    bands = d.balance_bands(W / 32 + rows.cpu().numpy(), W, world)   # (a row that holds nothing costs about as much as 240 covered pixels: tools/c4_band_times.py)
     comp = d.BandCompositor(bands, rank, world, f"cuda:{local_rank}", dst=0, slots=2)
     targets = []
     for slot in range(2):
