@@ -342,7 +342,9 @@ def main():
         n_tiles = ((W + tile - 1) // tile) * ((H + tile - 1) // tile) * views
         by = kernel_bytes(stats, n_tiles)
         kernels = {k: stage_ms[k + "_ms"] for k in STAGES}
-        if kernels["clear"] < 0.003:     # the start of the pass rode along with the vertex kernel (a draw of a few views): one launch, both byte counts
+        if views <= 8 and V:     # the start of the pass rides along with the vertex kernel (a draw of a few views): one launch -- which the
+            # library's events book under the first of the two stages --, both byte counts
+            kernels["vertex"] += kernels["clear"]; kernels["clear"] = 0.0
             by["vertex"] += by["clear"]; by["clear"] = 0
         dom = max(kernels, key=kernels.get)
         achieved = by[dom] / (kernels[dom] * 1e-3) / 1e9
