@@ -191,7 +191,7 @@ SR_API int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ub
  * copy until the process ends -- and the call issues kernels only: no hipMalloc, hipFree, hipHostMalloc, event creation or
  * copy from host memory (the transforms travel as kernel arguments).
  * Limits: at most 8 views per call; the draw must fit the array in one pass (about 1 M triangles for one view: 48 bytes
- * per triangle and 16 per vertex, per view), else SR_ERR_UNSUPPORTED with the sizes in sr_last_error_string(); a frame
+ * per triangle and 12 per vertex, per view), else SR_ERR_UNSUPPORTED with the sizes in sr_last_error_string(); a frame
  * whose tile reference list does not fit what is left of the array reports the same when its target is next read.
  * All calls on one GPU share that GPU's array, which still holds the previous call's contents (what must start at zero is
  * zeroed by the draw itself): calls on one device handle are ordered by its stream; calls through DIFFERENT device handles
