@@ -338,7 +338,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         frames_per_s = world * views * args.steps / elapsed
         mtris = (T // views) * frames_per_s / 1e6
-        tile = 64 if samples == 1 else 32
+        tile = 32 if max(W, H) <= 8192 or samples != 1 else 64
         n_tiles = ((W + tile - 1) // tile) * ((H + tile - 1) // tile) * views
         by = kernel_bytes(stats, n_tiles)
         kernels = {k: stage_ms[k + "_ms"] for k in STAGES}
