@@ -39,9 +39,9 @@ def build_emulation_library():
     build_emu.build()   # once, before child processes race to build it
 
 
-# device-level knobs under which every frame must stay the same: smaller tiles, a tile reference list that overflows on
+# device-level knobs under which every frame must stay the same: the other tile size (64 x 64 at one sample, 16 x 16 at four), a tile reference list that overflows on
 # every first frame, a scratch budget that splits batches into passes
-KNOBS = [dict(SR_TILE_LOG2="5", SR_FILL_BLOCKS="1"), dict(SR_REF_CAPACITY="16"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4")]
+KNOBS = [dict(SR_TILE_LOG2="6", SR_FILL_BLOCKS="1"), dict(SR_REF_CAPACITY="16"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4")]
 _child_runs = {}
 
 
@@ -161,7 +161,7 @@ def test_scene_driver_under_address_and_ub_sanitizers():
     exe = build_emu.build_sanitized()
     env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     runs = [(k, subprocess.Popen([exe], env=dict(env, **k), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-            for k in ({}, dict(SR_TILE_LOG2="5"), dict(SR_REF_CAPACITY="16", SR_SCRATCH_MIB="1"))]
+            for k in ({}, dict(SR_TILE_LOG2="6"), dict(SR_REF_CAPACITY="16", SR_SCRATCH_MIB="1"))]
     for k, proc in runs:
         out, _ = proc.communicate(timeout=1200)
         assert proc.returncode == 0 and "ok: 32 draws" in out and "runtime error" not in out and "AddressSanitizer" not in out, f"knobs {k}:\n{out[-3000:]}"
