@@ -458,6 +458,27 @@ def test_more_distinct_tiles_than_a_binning_block_can_hash(sr, oracle):
         dev.close()
 
 
+def test_both_tile_sizes_at_one_sample_give_the_same_frame(sr, oracle, device):
+    """At one sample the tile rasteriser works on 32 x 32 tiles, and on 64 x 64 ones (SR_TILE_LOG2=6) for frames of more than 8192
+    pixels along an axis: both must give the oracle's frame -- here a few views of large triangles, which all take the tile path."""
+    verts, idx = sr.scene.uv_sphere(24, 16)
+    n_views, W, H = 3, 400, 300
+    ubos = sr.scene.orbit_ubos(n_views, W, H)
+    images = sr.scene.material_textures(32)
+    dev = util.device_with_env(sr, SR_TILE_LOG2="6")
+    try:
+        large = util.gpu_render(sr, dev, verts, idx, images, ubos, W, H, 1)
+        small = util.gpu_render(sr, device, verts, idx, images, ubos, W, H, 1)
+        assert large[0]["stats"]["tile_refs"] > 0 and small[0]["stats"]["tile_refs"] > large[0]["stats"]["tile_refs"]
+        for k in range(n_views):
+            ref = oracle.draw(ubos[k], verts, idx, images, W, H, 1)
+            _check_view(large[k], ref)
+            _check_view(small[k], ref)
+            assert np.array_equal(large[k]["vis"], small[k]["vis"]) and np.array_equal(large[k]["bgra"], small[k]["bgra"])
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("samples", [1, 4])
 def test_view_batch_split_into_passes(sr, oracle, device, samples):
     """BASELINE config 5 in small: more views than the per-view scratch budget holds at once, so one draw
