@@ -1844,6 +1844,11 @@ void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32
     fill_kernel<<<dim3(chunk_grid(b), n_views), 256, 0, st>>>(g, b);
 }
 
+// work-items per workgroup of the one-sample rasteriser on 32 x 32 tiles (measured on the 64-view 1080p batch: 512 -> 0.64 ms, 256 -> 0.46,
+// 128 -> 0.40, 64 -> 0.40: a tile's few dozen references keep two waves busy, more only wait at its barriers)
+#ifndef SR_RASTER_TPB_51
+#define SR_RASTER_TPB_51 128
+#endif
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
                    uint64_t* vis, const BlockFlags& flags, uint32_t view0, uint32_t n_views)
 {
@@ -1851,7 +1856,7 @@ void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const S
     const dim3 grid((uint32_t)(g.tiles_x * g.tiles_y), n_views);
     unsigned long long* v = (unsigned long long*)vis;
     if (g.samples == 1 && g.tile_log2 == 6) raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
-    else if (g.samples == 1 && g.tile_log2 == 5) raster_kernel<5, 1, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
+    else if (g.samples == 1 && g.tile_log2 == 5) raster_kernel<5, 1, SR_RASTER_TPB_51><<<grid, SR_RASTER_TPB_51, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
     // (512 work-items, not 1024: at 1024 the kernel is capped at 128 registers and spills 500 bytes per work-item; measured 133 vs 386 us
     // on the reference's own 800x600 4-sample frame)
     else if (g.samples == 4 && g.tile_log2 == 5) raster_kernel<5, 4, 512><<<grid, 512, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
