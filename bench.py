@@ -42,6 +42,7 @@ WORKLOADS = {
     "c2_1080p_64views": (1920, 1080, 88, 88, 2048, 2048, 1, 64, 0),          # BASELINE config 2: one draw of 64 cameras
     "c5_50Mtri_views": (1920, 1080, 5000, 5000, 2048, 2048, 1, 128, 1024),   # BASELINE config 5: this GPU's 128 of 1024 cameras, 50 M triangles
     "c4_8k_10Mtri": (7680, 4320, 2500, 2000, 4096, 2048, 1, 1, 0),           # BASELINE config 4's frame whole, on one GPU (--mode sortfirst splits it over the ranks)
+    "mid_4k_8views": (3840, 2160, 300, 300, 2048, 2048, 1, 8, 0),            # 180 k triangles of some fifty pixels, 8 views: everything takes the tile lists
     "c5_small": (480, 270, 300, 300, 256, 128, 1, 8, 64),                    # config 5's code path at a size a CPU rehearsal can run
 }
 STAGES = ("clear", "vertex", "setup", "bin", "scan", "fill", "raster", "fragment")

@@ -195,7 +195,12 @@ __device__ inline uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __b
 #endif
 constexpr uint32_t kSetupTris = SR_SETUP_TRIS;               // triangles per lane of the set-up kernel
 constexpr uint32_t kSetupBlockTris = 256u * kSetupTris;      // triangles per set-up block
-constexpr uint32_t kTrisPerThread = 4;                       // triangles per lane of the binning kernel
+// (one triangle per lane: measured against two and four on the reference's 800 x 600 frame -- binning 15, 21, 31 us --, on the 64-view batch
+// and on 8 views of 390 000 fifty-pixel triangles at 4K -- 28, 30, 40 us: a lane's triangles go through the hash table one after the other)
+#ifndef SR_BIN_TRIS
+#define SR_BIN_TRIS 1
+#endif
+constexpr uint32_t kTrisPerThread = SR_BIN_TRIS;             // triangles per lane of the binning kernel
 constexpr uint32_t kBlockTris = 256u * kTrisPerThread;       // triangles per chunk of the pending list
 constexpr uint32_t kBlockRecords = kBlockTris * kMaxSmallTiles;
 constexpr uint32_t kHashBits = 11;
