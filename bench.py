@@ -145,7 +145,26 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [p.wait() for p in procs]
+    # a rank that dies (no such GPU, out of memory) would leave the others waiting in the rendezvous or a collective until a
+    # time-out: stop them as soon as one has failed
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            failed = next(abs(c) for c in codes if c not in (None, 0))
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill(); codes[i] = p.wait()
+            raise SystemExit(failed)   # the code of the rank that failed, not of the ones stopped because of it
+        time.sleep(0.2)
     raise SystemExit(max(abs(c) for c in codes))
 
 
