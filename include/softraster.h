@@ -184,7 +184,9 @@ SR_API int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ub
                    uint32_t n_views, size_t ubo_stride, const sr_texture textures[4]);
 
 /* ---- sr_draw for callers that cannot allocate.  No counterpart in the reference.  For callers that must not trigger
- * a device allocation while they draw: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * a device allocation while they draw: tight serving loops, harnesses that forbid hipMalloc, code that holds a HIP graph
+ * capture open on ANOTHER stream (the kernels go to the library's own stream and the call reads the previous draw's counters on
+ * the host, so the call itself cannot be captured into a graph).
  * Same arguments, same frame and same asynchrony as sr_draw, but every intermediate buffer of the draw (window-space
  * vertices, binning state, pending and reference lists, clip list, per-view transforms) lives in one array of
  * sr_no_alloc_scratch_bytes() = 64 MiB inside the library's device image -- each GPU the library runs on holds its own
@@ -192,7 +194,9 @@ SR_API int sr_draw(sr_device dev, sr_target target, sr_mesh mesh, const void* ub
  * copy from host memory (the transforms travel as kernel arguments).
  * Limits: at most 8 views per call; the draw must fit the array in one pass (about 1 M triangles for one view: 48 bytes
  * per triangle and 12 per vertex, per view), else SR_ERR_UNSUPPORTED with the sizes in sr_last_error_string(); a frame
- * whose tile reference list does not fit what is left of the array reports the same when its target is next read.
+ * whose tile reference list does not fit what is left of the array reports the same when its target is next read, and
+ * so does a frame with more than 1024 triangles per call that cross the near plane or the guard band (the clip list of this
+ * entry point holds 1024 entries where sr_draw's holds 65536): such a frame would be incomplete and is not handed over.
  * All calls on one GPU share that GPU's array, which still holds the previous call's contents (what must start at zero is
  * zeroed by the draw itself): calls on one device handle are ordered by its stream; calls through DIFFERENT device handles
  * of the same GPU that overlap in time race on the array and must not be made.

@@ -136,6 +136,67 @@ def test_fragments_exactly_on_the_far_plane(sr, oracle, device, samples):
     assert (inside != sr.NO_TRIANGLE).any() and (inside == sr.NO_TRIANGLE).any()
 
 
+def _window_triangles(sr, W, H, tris):
+    """Triangles given in window coordinates (x, y in pixels, z in 0..1) under identity matrices; each is turned front-facing."""
+    eye = np.eye(4, dtype=np.float32)
+    ubo = sr.scene.make_ubo(eye, eye, eye, (0.0, 0.0, 0.0))
+    out = []
+    for t in tris:
+        t = np.asarray(t, np.float64)
+        if (t[1, 0] - t[0, 0]) * (t[2, 1] - t[0, 1]) - (t[2, 0] - t[0, 0]) * (t[1, 1] - t[0, 1]) >= 0:   # clockwise on the y-down window = front
+            t = t[::-1]
+        ndc = np.stack([t[:, 0] / (W / 2) - 1.0, 1.0 - t[:, 1] / (H / 2), t[:, 2]], axis=1)
+        out.append(ndc)
+    verts = np.zeros((3 * len(out), 8), np.float32)
+    verts[:, :3] = np.concatenate(out)
+    verts[:, 5] = 1.0
+    verts[:, 6:8] = verts[:, :2]
+    return ubo, verts, np.arange(3 * len(out), dtype=np.uint32)
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_tall_and_wide_slivers_then_another_scene_in_the_same_target(sr, oracle, device, samples):
+    """Triangles one pixel wide and a few dozen rows tall (and the transpose) are resolved by the set-up kernel itself; their
+    boxes reach over several of the 32 x 8-pixel blocks the shading pass and the next draw's clear go by.  Every block must be
+    shaded in this draw and cleared by the next one: a second, unrelated scene (a large triangle BEHIND where the slivers were)
+    is drawn into the same target and must show nothing of the first."""
+    W, H = 160, 96
+    slivers = [
+        [[40.2, 5.0, 0.2], [41.4, 5.2, 0.2], [40.8, 29.0, 0.2]],       # 1 x 24 pixels: block rows 0..3
+        [[90.3, 33.1, 0.3], [91.2, 33.0, 0.3], [90.7, 64.9, 0.3]],     # 1 x 31: block rows 4..8
+        [[8.1, 70.3, 0.25], [39.9, 70.6, 0.25], [8.0, 71.4, 0.25]],    # 31 x 1: two block columns
+        [[120.2, 10.0, 0.2], [122.3, 10.1, 0.2], [121.0, 25.9, 0.2]],  # 2 x 16
+    ]
+    if samples == 4:   # the direct path takes boxes of at most 8 pixels at four samples
+        slivers = [[[40.1, 5.1, 0.2], [40.95, 5.2, 0.2], [40.6, 12.9, 0.2]], [[90.3, 30.1, 0.3], [90.9, 30.0, 0.3], [90.7, 37.9, 0.3]],
+                   [[60.1, 70.3, 0.25], [67.9, 70.6, 0.25], [60.0, 70.9, 0.25]]]
+    ubo, verts, idx = _window_triangles(sr, W, H, slivers)
+    behind = [[[2.0, 2.0, 0.6], [158.0, 3.0, 0.6], [70.0, 94.0, 0.6]]]
+    ubo2, verts2, idx2 = _window_triangles(sr, W, H, behind)
+    images = sr.scene.material_textures(16)
+    tex = [sr.create_texture(device, im) for im in images]
+    m1, m2 = sr.create_mesh_from_data(device, verts, idx), sr.create_mesh_from_data(device, verts2, idx2)
+    tgt = sr.RenderTarget(device, W, H, samples=samples)
+    try:
+        for mesh, (u, v, i) in ((m1, (ubo, verts, idx)), (m2, (ubo2, verts2, idx2)), (m1, (ubo, verts, idx)), (m1, (ubo, verts, idx))):
+            sr.draw(device, tgt, mesh, u, tex)
+            got = {"tri": tgt.read_triangle_ids(0), "depth": tgt.read_depth(0), "bgra": tgt.read_color(0)}
+            ref = oracle.draw(u, v, i, images, W, H, samples)
+            util.assert_visibility_equal(got, ref)
+            assert np.array_equal(got["bgra"][..., 3], ref["bgra"][..., 3])
+            frac, worst = util.color_match_fraction(got["bgra"], ref["bgra"])
+            assert frac >= 0.9995, (frac, worst)    # (a sliver is a few dozen pixels of the 15 360: an unshaded block must not pass)
+            if mesh is m1:
+                st = tgt.stats()
+                assert st["triangles_direct"] == len(slivers) and st["triangles_binned"] == 0, st
+                rows_covered = (ref["tri"].reshape(H, W, samples)[:, :, 0] != sr.NO_TRIANGLE).any(axis=1).sum()
+                assert rows_covered >= (25 if samples == 1 else 6)    # (a sliver narrows towards its far end: not every row of its box holds a covered sample)
+    finally:
+        tgt.destroy(); m1.destroy(); m2.destroy()
+        for t in tex:
+            t.destroy()
+
+
 def test_empty_mesh_and_offscreen_mesh(sr, oracle, device):
     images = sr.scene.material_textures(16)
     ubo = sr.scene.default_camera_ubo(128, 96)

@@ -80,6 +80,25 @@ def test_limits_are_reported(sr, device):
         sr.draw(device, tgt, mesh, sr.scene.default_camera_ubo(320, 200), tex)              # the ordinary entry point takes it
         assert (tgt.read_triangle_ids(0) != sr.NO_TRIANGLE).any()
         tgt.destroy(); mesh.destroy()
+        # more triangles through the eye plane than this entry point's clip list holds (1024): reported when the target is read,
+        # not handed over with triangles missing; the ordinary entry point (65536 entries) draws the frame
+        import util
+        rng = np.random.default_rng(5)
+        verts = np.zeros((3 * 1800, 8), np.float32)
+        verts[:, :3] = rng.uniform(-2.0, 2.0, size=(3 * 1800, 3))
+        verts[:, 5] = 1.0
+        idx = np.arange(3 * 1800, dtype=np.uint32)
+        eye = np.array([0.0, 0.0, 0.0])
+        ubo = sr.scene.make_ubo(np.eye(4, dtype=np.float32), sr.scene.look_at(eye, (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)), sr.scene.perspective(0.8, 1.6, 0.1, 10.0), eye)
+        mesh = sr.create_mesh_from_data(device, verts, idx)
+        tgt = sr.RenderTarget(device, 160, 100)
+        sr.draw(device, tgt, mesh, ubo, tex, no_alloc=True)
+        with pytest.raises(sr.SoftRasterError) as e:
+            tgt.read_triangle_ids(0)
+        assert e.value.status == -5 and "clip list" in str(e.value)
+        sr.draw(device, tgt, mesh, ubo, tex)
+        assert tgt.stats()["triangles_clipped"] > 1024 and tgt.stats()["triangles_unprojectable"] == 0
+        tgt.destroy(); mesh.destroy()
     finally:
         for t in tex:
             t.destroy()

@@ -127,6 +127,7 @@ struct sr_target_t {
     uint32_t passes = 0;
     uint32_t* h_counters = nullptr; void* hd_counters = nullptr; size_t h_counters_cap = 0;   // pinned + mapped, [passes][8], written by the scan kernel of the last draw
     uint64_t capacity_at_draw = 0;
+    uint32_t clip_capacity_at_draw = 0;
     uint64_t total_refs = 0, unprojectable = 0, binned = 0, micro = 0, clipped = 0;
     // A frame of nothing but micro-triangles leaves the binning, clipping, scan, fill and tile kernels without work, yet
     // each costs a launch and a chain of dependent loads (30 us of a 240 us frame).  When the previous draw of this
@@ -369,6 +370,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(hipGetLastError());
     tg->passes = passes;
     tg->capacity_at_draw = ps.ref_capacity;
+    tg->clip_capacity_at_draw = ps.clip_capacity;
     tg->check_pending = true;
     return SR_OK;
 }
@@ -387,6 +389,9 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
         }
         tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned; tg->micro = micro; tg->clipped = clipped;
         const bool lean_missed = tg->lean && (binned > 0 || listed > 0);    // drawn without the kernels it turned out to need
+        if (tg->no_alloc && listed > tg->clip_capacity_at_draw)   // the header promises sr_draw's frame or an error, never a frame with triangles missing
+            return fail(SR_ERR_UNSUPPORTED, "sr_draw_no_alloc: " + std::to_string(listed) + " triangles cross the near plane or the guard band, the clip list of this entry point holds " +
+                                                std::to_string(tg->clip_capacity_at_draw) + " (use sr_draw)");
         if (!lean_missed && worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
         if (attempt == 2) break;
         if (lean_missed) tg->lean = false;

@@ -98,10 +98,7 @@ __global__ __launch_bounds__(64) void store_views_kernel(ViewPack pack, uint32_t
 // 5 M vertices), G = 2 for the view batch.
 // =================================================================================================
 constexpr uint32_t kFusedVertexGroup = 4, kBatchVertexGroup = 2;
-#ifndef SR_VERTEX_VIEWS
-#define SR_VERTEX_VIEWS 8
-#endif
-constexpr uint32_t kVertexViewsPerBlock = SR_VERTEX_VIEWS;   // views a workgroup of the batch vertex kernel goes through with its positions loaded once
+constexpr uint32_t kVertexViewsPerBlock = 8;   // views a workgroup of the batch vertex kernel goes through with its positions loaded once
 template <uint32_t G> struct VecOf;
 template <> struct VecOf<1> { typedef float F; typedef int2 I; };
 template <> struct VecOf<2> { typedef float2 F; typedef int4 I; };
@@ -177,34 +174,40 @@ __device__ inline uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __b
 #ifndef SR_SETUP_TRIS
 #define SR_SETUP_TRIS 3
 #endif
-// Build-time tuning knobs (tools/exp_build.py builds variants of the library with them for A/B runs on the GPU; the
-// defaults are what was measured best): triangles per lane of the set-up kernel (measured on the 10 M-triangle frame with the
+// Build-time tuning knobs.  tools/exp_build.py builds variants of the library with them for A/B runs on the GPU, and refuses to write
+// a variant whose sources, built for the CPU with the same flags, do not pass the emulated kernel tests first; each knob's legal
+// range is asserted where it is used.  The defaults are what was measured best: triangles per lane of the set-up kernel (measured on the 10 M-triangle frame with the
 // depths gathered and the samples resolved by the lane that set the triangle up: 1 -> 210 us, 2 -> 131 us, 3 -> 82 us,
 // 4 -> 83 us, 6 -> 88 us, 8 -> 97 us -- what counts is the number of independent gathers a lane has in flight, until the
 // registers they need cost occupancy; with the covered triangles queued for a second phase: 3 -> 77.8 us, 4 -> 78.0 us,
 // 6 -> 79 us, 8 -> 81 us, and the 50 M-triangle view batch 22.3 instead of 29.1 ms), and optional occupancy targets (waves per SIMD) that make the compiler fit the set-up / shading kernel into fewer registers.
 #ifdef SR_SETUP_WAVES
+static_assert(SR_SETUP_WAVES >= 1 && SR_SETUP_WAVES <= 8, "SR_SETUP_WAVES: waves per SIMD, 1..8");
 #define SR_SETUP_ATTR __attribute__((amdgpu_waves_per_eu(SR_SETUP_WAVES, SR_SETUP_WAVES)))
 #else
 #define SR_SETUP_ATTR
 #endif
 #ifdef SR_FRAG_WAVES
+static_assert(SR_FRAG_WAVES >= 1 && SR_FRAG_WAVES <= 8, "SR_FRAG_WAVES: waves per SIMD, 1..8");
 #define SR_FRAG_ATTR __attribute__((amdgpu_waves_per_eu(SR_FRAG_WAVES, SR_FRAG_WAVES)))
 #else
 #define SR_FRAG_ATTR
 #endif
 constexpr uint32_t kSetupTris = SR_SETUP_TRIS;               // triangles per lane of the set-up kernel
+static_assert(kSetupTris >= 1u && kSetupTris <= 8u, "SR_SETUP_TRIS: 1..8 triangles per lane (the LDS queue holds 256 * kSetupTris entries of 16 bytes, twice in the view loop)");
 constexpr uint32_t kSetupBlockTris = 256u * kSetupTris;      // triangles per set-up block
 // (one triangle per lane: measured against two and four on the reference's 800 x 600 frame -- binning 15, 21, 31 us --, on the 64-view batch
 // and on 8 views of 390 000 fifty-pixel triangles at 4K -- 28, 30, 40 us: a lane's triangles go through the hash table one after the other)
-#ifndef SR_BIN_TRIS
-#define SR_BIN_TRIS 1
-#endif
-constexpr uint32_t kTrisPerThread = SR_BIN_TRIS;             // triangles per lane of the binning kernel
+constexpr uint32_t kTrisPerThread = 1;                       // triangles per lane of the binning kernel
 constexpr uint32_t kBlockTris = 256u * kTrisPerThread;       // triangles per chunk of the pending list
 constexpr uint32_t kBlockRecords = kBlockTris * kMaxSmallTiles;
 constexpr uint32_t kHashBits = 11;
 constexpr uint32_t kHashSize = 1u << kHashBits;
+// The table must be able to hold a chunk's (triangle, tile) pairs at a load that keeps the probe sequences short (pairs that find no
+// slot fall back to the per-tile path, which is correct but slow), and the loops that initialise and walk it below move whole
+// 16-byte groups per work-item.
+static_assert(kHashSize >= 4u && (kHashSize & (kHashSize - 1u)) == 0u, "the binning hash table is a power of two of at least one uint4");
+static_assert(kHashSize >= kBlockRecords, "the binning hash table holds every (triangle, tile) pair of a chunk");
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kHashProbes = 24;
 // slot of `tile` in the block's table, or kHashSize if the table is too crowded (the caller then
@@ -333,10 +336,7 @@ __device__ inline bool sample_box_wrapping(int mnx, int mxx, int mny, int mxy, c
 // L2s and the lines of the visibility buffer travel between them under the atomic mins.  xcd_runs renumbers the workgroups so that
 // each XCD works through runs of kXcdRun consecutive logical ids (short enough that the eight stay evenly loaded).  A bijection on
 // [0, n): the ids past the last whole group of 8 * kXcdRun keep their number.
-#ifndef SR_XCD_RUN
-#define SR_XCD_RUN 64
-#endif
-constexpr uint32_t kXcdRun = SR_XCD_RUN;
+constexpr uint32_t kXcdRun = 64;
 __device__ inline uint32_t xcd_runs(uint32_t b, uint32_t n)
 {
     if (kXcdRun <= 1u || b >= n / (8u * kXcdRun) * (8u * kXcdRun)) return b;
@@ -505,12 +505,15 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
                 const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
                 drawn = micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_view, g);
                 if (drawn) {
-                    // the blocks the box reaches into now hold something (one block as a rule, four at most: a box is smaller than a block)
+                    // every block the box reaches into may hold something now.  One block as a rule; a box of up to micro_pixels
+                    // pixels can be a sliver one pixel wide and 32 rows tall (five rows of blocks) or the transpose (two columns).
+                    static_assert(micro_pixels<S>() <= (int)kFlagBlockW, "a micro-triangle's box spans two block columns at most");
                     const uint32_t bx0 = (uint32_t)(x0 - g.rx) / kFlagBlockW, bx1 = (uint32_t)(x0 + npx - 1 - g.rx) / kFlagBlockW;
                     const uint32_t by0 = (uint32_t)(y0 - g.ry) / kFlagBlockH, by1 = (uint32_t)(y0 + npy - 1 - g.ry) / kFlagBlockH;
-                    flags.at(view0 + view, bx0, by0) = 1u;
-                    if (bx1 != bx0) flags.at(view0 + view, bx1, by0) = 1u;
-                    if (by1 != by0) { flags.at(view0 + view, bx0, by1) = 1u; if (bx1 != bx0) flags.at(view0 + view, bx1, by1) = 1u; }
+                    for (uint32_t by = by0; by <= by1; ++by) {
+                        flags.at(view0 + view, bx0, by) = 1u;
+                        if (bx1 != bx0) flags.at(view0 + view, bx1, by) = 1u;
+                    }
                 }
             }
             n_micro += (uint32_t)__popcll(__ballot(drawn));   // of the wave
@@ -570,10 +573,9 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
     __syncthreads();   // the tables of the previous chunk are no longer in use
     uint32_t* count_small = b.count_small + (size_t)view * n_tiles;
     uint32_t* count_large = b.count_large + (size_t)view * n_tiles;
-#pragma unroll
-    for (uint32_t k = 0; k < kHashSize / 1024u; ++k) {
-        reinterpret_cast<uint4*>(s_key)[tid + 256u * k] = make_uint4(kHashEmpty, kHashEmpty, kHashEmpty, kHashEmpty);
-        reinterpret_cast<uint4*>(s_cnt)[tid + 256u * k] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t e = tid; e < kHashSize / 4u; e += 256u) {   // (any table size: no trip count that rounds down to nothing)
+        reinterpret_cast<uint4*>(s_key)[e] = make_uint4(kHashEmpty, kHashEmpty, kHashEmpty, kHashEmpty);
+        reinterpret_cast<uint4*>(s_cnt)[e] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (tid == 0) s_total = 0u;
 
@@ -690,9 +692,8 @@ __global__ __launch_bounds__(256) void bin_kernel(const uint32_t* __restrict__ i
     __syncthreads();
     // one returning global atomic per distinct tile of the block reserves the group's place in the
     // tile's list; the slot then holds the group's first position
-#pragma unroll
-    for (uint32_t k = 0; k < kHashSize / 256u; ++k) {
-        const uint32_t e = tid + 256u * k, c = s_cnt[e];
+    for (uint32_t e = tid; e < kHashSize; e += 256u) {
+        const uint32_t c = s_cnt[e];
         if (c) s_cnt[e] = atomicAdd(&count_small[s_key[e]], c);
     }
     __syncthreads();
@@ -1851,9 +1852,7 @@ void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32
 
 // work-items per workgroup of the one-sample rasteriser on 32 x 32 tiles (measured on the 64-view 1080p batch: 512 -> 0.64 ms, 256 -> 0.46,
 // 128 -> 0.40, 64 -> 0.40: a tile's few dozen references keep two waves busy, more only wait at its barriers)
-#ifndef SR_RASTER_TPB_51
-#define SR_RASTER_TPB_51 128
-#endif
+constexpr int kRasterTpb51 = 128;
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
                    uint64_t* vis, const BlockFlags& flags, uint32_t view0, uint32_t n_views)
 {
@@ -1861,7 +1860,7 @@ void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const S
     const dim3 grid((uint32_t)(g.tiles_x * g.tiles_y), n_views);
     unsigned long long* v = (unsigned long long*)vis;
     if (g.samples == 1 && g.tile_log2 == 6) raster_kernel<6, 1, 1024><<<grid, 1024, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
-    else if (g.samples == 1 && g.tile_log2 == 5) raster_kernel<5, 1, SR_RASTER_TPB_51><<<grid, SR_RASTER_TPB_51, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
+    else if (g.samples == 1 && g.tile_log2 == 5) raster_kernel<5, 1, kRasterTpb51><<<grid, kRasterTpb51, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
     // (512 work-items, not 1024: at 1024 the kernel is capped at 128 registers and spills 500 bytes per work-item; measured 133 vs 386 us
     // on the reference's own 800x600 4-sample frame)
     else if (g.samples == 4 && g.tile_log2 == 5) raster_kernel<5, 4, 512><<<grid, 512, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
