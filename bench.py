@@ -34,6 +34,20 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
+# Set only by tests/emu/rehearse.py: the multi-rank code paths of this script run end to end on CPUs -- ranks talk over gloo, the
+# collectives' tensors live in host memory, every rank opens "device 0" of the CPU build of the kernels.  Never set on a GPU box.
+CPU_REHEARSAL = os.environ.get("SR_BENCH_CPU_REHEARSAL") == "1"
+
+
+def tensor_device(local_rank):
+    return "cpu" if CPU_REHEARSAL else f"cuda:{local_rank}"
+
+
+def gpu_synchronize():
+    if not CPU_REHEARSAL:
+        import torch
+        torch.cuda.synchronize()
+
 WORKLOADS = {
     # name: (width, height, sphere X, sphere Y, albedo size, other maps size, samples, views per GPU, cameras of the whole orbit (0: per-rank camera))
     "c3_4k_10Mtri": (3840, 2160, 2500, 2000, 4096, 2048, 1, 1, 0),          # the headline: BASELINE config 3
@@ -71,7 +85,8 @@ def kernel_bytes(st, n_tiles):
     vertex_reads = reads_per_view(V // views, 512, fused=views <= 8, cap=8)
     index_reads = reads_per_view(T // views, 768)
     return {
-        "clear": P * S * 8,                                                   # visibility words written (only the covered blocks are; counted in full)
+        "clear": Pv * S * 8,                                                  # visibility words that held something and have to be cleared (the covered pixels' words; the
+                                                                              # 32 x 8-pixel blocks the kernel clears hold a few more)
         "vertex": V * 12 * vertex_reads + V * 12,                              # positions read, xy + z planes written
         "setup": T * 12 * index_reads + V * 8 + min(V, 3 * Fd) * 4 + direct_samples * 8 + B * 4,   # indices, xy plane, z of covered micro-triangles, atomic-min words, pending ids
         "bin": B * 4 + B * 12 + min(V, 3 * B) * 8 + R * 12,                   # pending ids, indices, xy, records
@@ -177,8 +192,11 @@ def init_ranks(args):
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if CPU_REHEARSAL:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     return rank, local_rank, world
@@ -192,26 +210,27 @@ def sort_first(args, sr, rank, local_rank, world):
     import torch
     import torch.distributed as dist
     from softraster import distributed as d
-    W, H = 7680, 4320
-    verts, idx = sr.scene.uv_sphere(2500, 2000)
-    images = [sr.scene.albedo_pattern(4096), None, sr.scene.gray_map(2048, 2048, 0, 254), sr.scene.gray_map(2048, 2048, 72, 255)]
+    W, H, SX, SY, alb_size, map_size = WORKLOADS[args.workload or "c4_8k_10Mtri"][:6]
+    verts, idx = sr.scene.uv_sphere(SX, SY)
+    images = [sr.scene.albedo_pattern(alb_size), None, sr.scene.gray_map(map_size, map_size, 0, 254), sr.scene.gray_map(map_size, map_size, 72, 255)]
     ubo = sr.scene.default_camera_ubo(W, H)
-    torch.cuda.set_device(local_rank)
-    dev = sr.Device(local_rank)
+    if not CPU_REHEARSAL:
+        torch.cuda.set_device(local_rank)
+    dev = sr.Device(0 if CPU_REHEARSAL else local_rank)
     mesh = sr.create_mesh_from_data(dev, verts, idx)
     tex = [sr.create_texture(dev, im, sampler=sr.default_sampler(1.0)) if im is not None else None for im in images]
     # cost profile: one frame over equal bands, covered pixels per row, summed over the ranks
     even = d.split_bands(W, H, world)
     probe = sr.RenderTarget(dev, W, H, samples=1, n_views=1, rect=even[rank])
     sr.draw(dev, probe, mesh, ubo, tex)
-    rows = torch.zeros(H, dtype=torch.float64, device=f"cuda:{local_rank}")
+    rows = torch.zeros(H, dtype=torch.float64, device=tensor_device(local_rank))
     covered = (probe.read_triangle_ids(0)[..., 0] != sr.NO_TRIANGLE).sum(axis=1).astype(np.float64)
     rows[even[rank][1]:even[rank][1] + even[rank][3]] = torch.from_numpy(covered).to(rows.device)
     probe.destroy()
     if world > 1:
         dist.all_reduce(rows)
     bands = d.balance_bands(W / 32 + rows.cpu().numpy(), W, world)   # (a row that holds nothing costs about as much as 240 covered pixels: tools/c4_band_times.py)
-    comp = d.BandCompositor(bands, rank, world, f"cuda:{local_rank}", dst=0, slots=2)
+    comp = d.BandCompositor(bands, rank, world, tensor_device(local_rank), dst=0, slots=2)
     targets = []
     for slot in range(2):
         t = sr.RenderTarget(dev, W, H, samples=1, n_views=1, rect=bands[rank])
@@ -227,32 +246,49 @@ def sort_first(args, sr, rank, local_rank, world):
 
     def drain():
         comp.wait(0); comp.wait(1)
-        torch.cuda.synchronize()
+        gpu_synchronize()
         if world > 1:
             dist.barrier()
 
     for i in range(max(args.warmup, 1)):
         step(i)
     drain()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    comp.wait(0); comp.wait(1)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed():
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        comp.wait(0); comp.wait(1)
+        gpu_synchronize()
+        return time.perf_counter() - t0
+
+    def alone():
+        """The same frame whole on rank 0's GPU (no bands, no exchange): the one-GPU point of this strong-scaling series."""
+        whole = sr.RenderTarget(dev, W, H, samples=1, n_views=1)
+        for _ in range(max(args.warmup, 1)):
+            sr.draw(dev, whole, mesh, ubo, tex)
+        dev.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sr.draw(dev, whole, mesh, ubo, tex)
+        dev.synchronize()
+        dt = time.perf_counter() - t0
+        whole.destroy()
+        return dt
+    alone_s, elapsed, _own = d.timed_alone_then_together(timed, rank, world, alone=alone, device=tensor_device(local_rank))
     if rank == 0:
         T = idx.size // 3
+        n1 = T * args.steps / alone_s / 1e6
         print(json.dumps({
-            "metric": "Mtris/s, 7680x4320 frame of a 10M-triangle mesh split sort-first over the GPUs", "value": round(T * args.steps / elapsed / 1e6, 2),
+            "metric": f"Mtris/s, {W}x{H} frame of a {T / 1e6:g}M-triangle mesh split sort-first over the GPUs", "value": round(T * args.steps / elapsed / 1e6, 2),
             "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "c4_8k_sort_first", "width": W, "height": H, "triangles": T, "bands": bands,
+            "config": {"workload": "c4_8k_sort_first" if (args.workload or "c4_8k_10Mtri") == "c4_8k_10Mtri" else args.workload + "_sort_first", "width": W, "height": H, "triangles": T, "bands": bands,
                        "composite": "point-to-point sends of BGRA8 bands into rank 0's frame (RCCL), double-buffered" if world > 1 else "none"},
-            "frames_per_s": round(args.steps / elapsed, 2)}), flush=True)
+            "frames_per_s": round(args.steps / elapsed, 2),
+            "n1_same_workload_Mtris_per_s": round(n1, 2), "n1_same_workload_ms_per_step": round(alone_s / args.steps * 1e3, 4),
+            "speedup_vs_n1_same_workload": round(T * args.steps / elapsed / 1e6 / n1, 3),
+            "n1_note": f"rank 0 drew the whole {W}x{H} frame alone, before the joint run, while the other ranks waited at a barrier"}), flush=True)
     drain()
     for t_ in tex:
         if t_ is not None:
@@ -302,7 +338,7 @@ def main():
     else:            # rank r draws view r of a `world`-camera orbit; view 0 is the reference's default camera
         ubo = sr.scene.default_camera_ubo(W, H, eye=sr.scene.orbit_eye(rank, max(world, 1)) if world > 1 else (2.0, 2.0, 2.0))
 
-    dev = sr.Device(local_rank)
+    dev = sr.Device(0 if CPU_REHEARSAL else local_rank)
     mesh = sr.create_mesh_from_data(dev, verts, idx)
     tex = [sr.create_texture(dev, im, sampler=sr.default_sampler(args.max_anisotropy)) if im is not None else None for im in images]
     tgt = sr.RenderTarget(dev, W, H, samples=samples, n_views=views)
@@ -310,11 +346,11 @@ def main():
     def barrier():
         dev.synchronize()
         if world > 1:
-            torch.cuda.synchronize()
+            gpu_synchronize()
             dist.barrier()
 
     def timed(textures, steps):
-        barrier()
+        dev.synchronize()    # (the barrier across ranks, where there are several, is the caller's: timed_alone_then_together)
         t0 = time.perf_counter()
         for _ in range(steps):
             sr.draw(dev, tgt, mesh, ubo, textures)
@@ -326,17 +362,20 @@ def main():
     stats = tgt.stats()
     stats["samples"] = samples
     stats["views"] = views
-    elapsed = own_elapsed = timed(tex, args.steps)
     if world > 1:
-        torch.cuda.synchronize()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        pv = torch.tensor([float(stats["shaded_pixels"])], dtype=torch.float64, device="cuda")
+        from softraster import distributed as d
+        # rank 0 first runs its share by itself (the one-GPU point of this series, same workload), the others waiting at a barrier;
+        # then every rank runs its share from a common barrier: max over the ranks
+        alone_s, elapsed, own_elapsed = d.timed_alone_then_together(lambda: timed(tex, args.steps), rank, world, device=tensor_device(local_rank))
+    else:
+        elapsed = own_elapsed = alone_s = timed(tex, args.steps)
+    if world > 1:
+        gpu_synchronize()
+        pv = torch.tensor([float(stats["shaded_pixels"])], dtype=torch.float64, device=tensor_device(local_rank))
         dist.all_reduce(pv, op=dist.ReduceOp.SUM)
         shaded_total = float(pv.item())
-        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(every, torch.tensor([own_elapsed], dtype=torch.float64, device="cuda"))
+        every = [torch.zeros(1, dtype=torch.float64, device=tensor_device(local_rank)) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([own_elapsed], dtype=torch.float64, device=tensor_device(local_rank)))
         per_rank_s = [float(e.item()) for e in every]
     else:
         shaded_total = float(stats["shaded_pixels"])
@@ -367,9 +406,11 @@ def main():
             kernels["vertex"] += kernels["clear"]; kernels["clear"] = 0.0
             by["vertex"] += by["clear"]; by["clear"] = 0
         dom = max(kernels, key=kernels.get)
+        traffic = measured_traffic(workload, dom)
         achieved = by[dom] / (kernels[dom] * 1e-3) / 1e9
         frame_bytes = frame_bytes_reference_model(stats)
-        metric = {"c3_4k_10Mtri": "Mtris/s, 3840x2160 frame of a 10M-triangle mesh with 4096^2 mip-mapped texture",
+        sampler = "trilinear sampler" if args.max_anisotropy <= 1.0 else f"maxAnisotropy {args.max_anisotropy:g} sampler"
+        metric = {"c3_4k_10Mtri": f"Mtris/s, 3840x2160 frame of a 10M-triangle mesh with 4096^2 mip-mapped texture ({sampler})",
                   "c5_50Mtri_views": "Mtris/s, 1024-camera batch of a 50M-triangle mesh at 1920x1080, sharded by view"}.get(workload, "Mtris/s")
         out = {
             "metric": metric,
@@ -392,15 +433,52 @@ def main():
             **({"frame_hbm_fraction_note": "the frame figure counts every view's mesh reads; a batch reads positions and indices once per pass of "
                                              f"{-(-views // max(stats.get('passes', 1), 1))} views, so this is not a fraction of what the kernels had to move"} if views > 1 else {}),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(workload, dom), "algorithmic_bytes": int(by[dom]),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes": int(by[dom]),
+                         # what the kernel really moved through HBM (PMC counters) per second, as a fraction of the peak: NOT the same as
+                         # `frac`, which prices the measurement plan's compulsory bytes -- the kernel skips the visibility words and the
+                         # colour of blocks that hold nothing, so it moves fewer bytes than the plan counts
+                         "hbm_utilisation": round(traffic / (kernels[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                          "kernel_source_digest": kernel_source_digest()},
         }
+        all_traffic = {k: measured_traffic(workload, k) for k in ("vertex", "setup", "fragment")}
+        if all(all_traffic.values()):
+            out["frame_hbm_utilisation"] = round(sum(all_traffic.values()) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if world > 1:
+            n1 = (T // views) * views * args.steps / alone_s / 1e6
+            out["n1_same_workload_Mtris_per_s"] = round(n1, 1)
+            out["n1_same_workload_ms_per_step"] = round(alone_s / args.steps * 1e3, 4)
+            out["speedup_vs_n1_same_workload"] = round(mtris / n1, 3)
+            out["n1_note"] = "rank 0 ran its own share alone, before the joint run, while the other ranks waited at a barrier (weak scaling: N ranks draw N shares)"
             # the default one-GPU line is the 4K headline frame, a different workload: the one-GPU point of THIS series is
             # `python bench.py --workload <this workload>`, and with no collective on the data path every rank's own rate
             # (per_gpu_Mtris_per_s) is what it measures
             out["scaling_note"] = (f"weak scaling by view, no collective: the N=1 point of this series is `python bench.py --workload {workload}` "
                                    "(each entry of per_gpu_Mtris_per_s is one GPU's rate on its share); the default N=1 line is the c3_4k_10Mtri headline, another workload")
+        if world == 1 and views == 1:
+            # The same draw under a moving camera (the reference's own use: an orbit driven by the keys, src/main.cpp:223-267, the block
+            # rewritten every frame, :988-1004): the eye advances one degree along the orbit every step, and, second figure, jumps a third
+            # of the way round it every step.  The timed loop above redraws one camera; what it leans on from frame to frame (lean
+            # draws, clears directed by the previous frame's flags, colour stores skipped where a block stays background) is counted here.
+            def moving(eyes):
+                ubos = [sr.scene.default_camera_ubo(W, H, eye=e) for e in eyes]
+                for u in ubos[:max(args.warmup, 1)]:
+                    sr.draw(dev, tgt, mesh, u, tex)
+                dev.synchronize()
+                before = dev.draw_counts()
+                t0 = time.perf_counter()
+                for u in ubos[max(args.warmup, 1):]:
+                    sr.draw(dev, tgt, mesh, u, tex)
+                dev.synchronize()
+                dt = time.perf_counter() - t0
+                after = dev.draw_counts()
+                return dt / args.steps * 1e3, {k: after[k] - before[k] for k in after}
+            n = args.steps + max(args.warmup, 1)
+            orbit_ms, orbit_counts = moving([sr.scene.orbit_eye(k, 360) for k in range(n)])
+            jump_ms, jump_counts = moving([sr.scene.orbit_eye((k * 127) % 360, 360) for k in range(n)])
+            out["ms_per_step_orbit"] = round(orbit_ms, 4)
+            out["ms_per_step_camera_jumps"] = round(jump_ms, 4)
+            out["moving_camera"] = {"orbit": dict(orbit_counts, step_degrees=1), "jumps": dict(jump_counts, step_degrees=127),
+                                    "note": "draws / lean_draws / lean_redraws / overflow_redraws of the timed steps; a lean redraw is a frame that had to be issued a second time in full"}
         if world == 1 and args.max_anisotropy <= 1.0:
             # the same frame through the sampler the reference creates (maxAnisotropy 16): a second figure, not the headline
             tex16 = [sr.create_texture(dev, im, sampler=sr.default_sampler(16.0)) if im is not None else None for im in images]

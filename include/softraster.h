@@ -81,6 +81,16 @@ typedef struct sr_draw_stats {
                                      buffers fit the budget; positions and indices are read once per pass, not once per view */
 } sr_draw_stats;
 
+/* How the draws of a device were issued since it was created (cumulative).  A draw whose target's previous draw of the same
+ * mesh and view count left nothing for the tile lists and the clipper is issued "lean" (without those kernels); if its own
+ * counters then show that it needed them, it is issued again in full before anything of it can be observed. */
+typedef struct sr_draw_counts {
+    uint64_t draws;               /* sr_draw / sr_draw_no_alloc calls that issued kernels */
+    uint64_t lean_draws;          /* of them, issued lean */
+    uint64_t lean_redraws;        /* lean draws that had to be issued again in full */
+    uint64_t overflow_redraws;    /* draws issued again because the tile reference list was too small */
+} sr_draw_counts;
+
 /* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */
 typedef struct sr_stage_times {
     float clear_ms, vertex_ms, setup_ms, bin_ms, scan_ms, fill_ms, raster_ms, fragment_ms, total_ms;
@@ -214,6 +224,9 @@ SR_API int sr_device_set_normal_mapping(sr_device dev, int enabled);
 
 /* ---- instrumentation (no reference counterpart) */
 SR_API int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out);
+/* Instrumentation, no reference counterpart: see sr_draw_counts.  Does not wait for anything; draws still in flight
+ * that turn out to need a second issue are counted when they are resolved (read-back, stats, synchronize). */
+SR_API int sr_device_get_draw_counts(sr_device dev, sr_draw_counts* out);
 /* When enabled, sr_draw brackets every stage with HIP events on the device's stream. */
 SR_API int sr_profile_enable(sr_device dev, int enabled);
 SR_API int sr_profile_get(sr_device dev, sr_stage_times* out);

@@ -29,9 +29,23 @@ def main():
                     "config", "roofline", "cpu_baseline"):
             assert key in out, key
         assert out["config"]["workload"] == workload and out["steps"] == 2 and out["value"] > 0
-        assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and out["roofline"]["bound"] == "hbm"
+        assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_utilisation"} and out["roofline"]["bound"] == "hbm"
+        if out["config"]["views_per_gpu"] == 1:     # the moving-camera companion of a one-view workload
+            assert out["ms_per_step_orbit"] > 0 and out["ms_per_step_camera_jumps"] > 0
+            assert out["moving_camera"]["orbit"]["draws"] == 2 and out["moving_camera"]["jumps"]["draws"] == 2
         assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "port"
         print("bench ok:", workload, out["counters"])
+    # the multi-rank paths (what the round-end driver runs on a whole node), two ranks over gloo on the CPU build
+    import subprocess
+    for extra in (["--workload", "c5_small"], ["--mode", "sortfirst", "--workload", "small_1080p_124ktri"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lib", softraster.LIB_PATH] + extra,
+                           env=dict(os.environ, SR_BENCH_CPU_REHEARSAL="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["n_gpus"] == 2 and out["value"] > 0 and out["n1_same_workload_Mtris_per_s"] > 0
+        ratio = out["value"] / out["n1_same_workload_Mtris_per_s"]      # (both rounded in the line: a few per cent of slack at these tiny rates)
+        assert abs(out["speedup_vs_n1_same_workload"] - ratio) < 0.05 * ratio + 0.02, (out["speedup_vs_n1_same_workload"], ratio)
+        print("bench ok: two ranks,", " ".join(extra), "speed-up over one rank on the same workload", out["speedup_vs_n1_same_workload"])
     import __graft_entry__
     __graft_entry__.smoke()
     print("smoke ok")

@@ -66,6 +66,28 @@ def _worker(rank, world, port, mode, q):
                 for f in range(3):
                     ok = ok and bool(np.array_equal(frames[f], oracle.draw(ubos[f], verts, idx, tex, W, H)["bgra"]))
                 q.put(ok)
+        elif mode == "alone_then_together":
+            # the timing protocol of the multi-GPU benchmark line: rank 0 runs the workload by itself while the others wait,
+            # then every rank runs its share from a common barrier
+            import time
+            windows = []
+
+            def timed():
+                t0 = time.monotonic(); time.sleep(0.15); t1 = time.monotonic()
+                windows.append((t0, t1))
+                return t1 - t0
+            alone_s, together_s, own_s = d.timed_alone_then_together(timed, rank, world)
+            every = [None] * world
+            dist.all_gather_object(every, (windows, alone_s, together_s, own_s))
+            if rank == 0:
+                ok = len(every[0][0]) == 2 and all(len(w[0]) == 1 for w in every[1:])          # rank 0 ran twice, the others once
+                solo = every[0][0][0]
+                joint = [every[0][0][1]] + [w[0][0] for w in every[1:]]
+                ok = ok and all(solo[1] <= j[0] for j in joint)                                   # nothing ran beside the solo run
+                ok = ok and max(j[0] for j in joint) < min(j[1] for j in joint)                  # the joint runs overlap: they started together
+                ok = ok and all(abs(e[1] - (solo[1] - solo[0])) < 1e-9 for e in every)            # every rank knows the solo time
+                ok = ok and all(abs(e[2] - max(x[3] for x in every)) < 1e-9 for e in every)       # and the max over the ranks
+                q.put(bool(ok))
         else:   # sort-last by view
             n_views = 5
             ubos = scene.orbit_ubos(n_views, W, H)
@@ -82,11 +104,11 @@ def _worker(rank, world, port, mode, q):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("mode", ["sort_first", "sort_last", "balanced_pipelined"])
+@pytest.mark.parametrize("mode", ["sort_first", "sort_last", "balanced_pipelined", "alone_then_together"])
 def test_ranks(mode, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + ["sort_first", "sort_last", "balanced_pipelined"].index(mode) * 2 + world // 4
+    port = 29500 + (os.getpid() % 2000) + ["sort_first", "sort_last", "balanced_pipelined", "alone_then_together"].index(mode) * 2 + world // 4
     procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()

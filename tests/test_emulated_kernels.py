@@ -183,12 +183,12 @@ def test_differential_fuzzing_against_the_oracle():
 
 
 def test_benchmark_and_smoke_scripts_run_end_to_end():
-    """tests/emu/rehearse.py: bench.py (three small workloads, one process) and __graft_entry__.smoke() against the CPU build
+    """tests/emu/rehearse.py: bench.py (three small workloads in one process, then its two multi-rank modes as two ranks over gloo) and __graft_entry__.smoke() against the CPU build
     of the kernels -- the scripts the round-end driver runs on the GPU box still produce their JSON line and their
     oracle comparison with the current library."""
     build_emulation_library()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "rehearse.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert r.returncode == 0 and r.stdout.count("bench ok:") == 3 and r.stdout.strip().endswith("smoke ok"), r.stdout[-3000:]
+    assert r.returncode == 0 and r.stdout.count("bench ok:") == 5 and r.stdout.strip().endswith("smoke ok"), r.stdout[-3000:]
 
 
 def test_file_readers_survive_mutated_files():

@@ -88,6 +88,7 @@ struct sr_device_t {
     size_t events_used = 0;
     std::vector<sr_target_t*> targets;   // live targets of this device (they may hold a reference to a mesh and textures)
     void* static_scratch = nullptr;      // this GPU's copy of the array `scratch` (sr_api.hip), looked up at creation
+    sr_draw_counts counts{};             // sr_device_get_draw_counts
 };
 
 struct sr_mesh_t {
@@ -394,10 +395,10 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
                                                 std::to_string(tg->clip_capacity_at_draw) + " (use sr_draw)");
         if (!lean_missed && worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
         if (attempt == 2) break;
-        if (lean_missed) tg->lean = false;
+        if (lean_missed) { tg->lean = false; ++dev->counts.lean_redraws; }
         else if (tg->no_alloc) return fail(SR_ERR_UNSUPPORTED, "sr_draw_no_alloc: the frame needs " + std::to_string(worst) + " tile references, the static scratch holds " +
                                                                     std::to_string(tg->capacity_at_draw) + " after this draw's other buffers (use sr_draw)");
-        else dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull);
+        else { dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull); ++dev->counts.overflow_redraws; }
         int rc = issue_draw(dev, tg);
         if (rc != SR_OK) return rc;
         SR_HIP(hipStreamSynchronize(dev->stream));
@@ -863,6 +864,8 @@ static int draw_common(sr_device dev, sr_target target, sr_mesh mesh, const void
     }
     target->drawn = true;
     target->no_alloc = no_alloc;
+    ++dev->counts.draws;
+    if (target->lean) ++dev->counts.lean_draws;
     return issue_draw(dev, target);
 }
 
@@ -922,6 +925,13 @@ int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out)
     out->triangles_direct = target->micro;
     out->triangles_clipped = target->clipped;
     out->passes = target->passes;
+    return SR_OK;
+}
+
+int sr_device_get_draw_counts(sr_device dev, sr_draw_counts* out)
+{
+    if (!dev || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = dev->counts;
     return SR_OK;
 }
 

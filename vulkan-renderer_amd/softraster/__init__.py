@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "sr_target_readback", "sr_draw", "sr_draw_get_stats", "sr_profile_enable", "sr_profile_get", "sr_debug_vertex_stage",
     "sr_texture_size", "sr_texture_create_from_file", "sr_image_read_file", "sr_image_free",
     "sr_model_load", "sr_model_mesh_count", "sr_model_mesh", "sr_model_destroy", "sr_model_read_file", "sr_model_mesh_data",
-    "sr_draw_no_alloc", "sr_no_alloc_scratch_bytes", "sr_device_set_normal_mapping",
+    "sr_draw_no_alloc", "sr_no_alloc_scratch_bytes", "sr_device_set_normal_mapping", "sr_device_get_draw_counts",
 )
 
 
@@ -55,6 +55,10 @@ class DrawStats(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class DrawCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("draws", "lean_draws", "lean_redraws", "overflow_redraws")]
 
 
 class StageTimes(C.Structure):
@@ -120,6 +124,7 @@ def load_library():
     L.sr_no_alloc_scratch_bytes.restype = sz
     L.sr_device_set_normal_mapping.argtypes = [vp, C.c_int]
     L.sr_draw_get_stats.argtypes = [vp, vp, C.POINTER(DrawStats)]
+    L.sr_device_get_draw_counts.argtypes = [vp, C.POINTER(DrawCounts)]
     L.sr_profile_enable.argtypes = [vp, C.c_int]
     L.sr_profile_get.argtypes = [vp, C.POINTER(StageTimes)]
     L.sr_debug_vertex_stage.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
@@ -179,6 +184,12 @@ class Device:
         """Draws issued from now on shade with the normal map's normals (shaders/shader.frag:35-53 with the body the reference
         has commented out restored); off by default, as in the reference."""
         _check(self._lib.sr_device_set_normal_mapping(self._h, int(enabled)), "sr_device_set_normal_mapping")
+
+    def draw_counts(self) -> dict:
+        """How the draws of this device were issued so far: draws, lean_draws, lean_redraws, overflow_redraws (cumulative)."""
+        c = DrawCounts()
+        _check(self._lib.sr_device_get_draw_counts(self._h, C.byref(c)), "sr_device_get_draw_counts")
+        return {n: int(getattr(c, n)) for n, _ in c._fields_}
 
     def profile(self, enabled: bool):
         _check(self._lib.sr_profile_enable(self._h, int(enabled)), "sr_profile_enable")

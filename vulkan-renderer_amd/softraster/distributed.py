@@ -119,6 +119,38 @@ class BandCompositor:
             torch.cuda.current_stream(self._local[slot].device).synchronize()   # because the renderer draws on a stream of its own
 
 
+def timed_alone_then_together(timed, rank: int, world: int, alone=None, device: str = "cpu", group=None):
+    """The timing protocol of a multi-rank benchmark line that carries its own one-rank point.
+
+    `timed()` runs this rank's share of the timed series and returns its duration in seconds; `alone()` (default:
+    `timed`) is what rank 0 runs by itself first -- the same workload on one GPU -- while every other rank waits at a
+    barrier and touches nothing.  Then all ranks start `timed()` together from a barrier.  Returns
+    (alone_seconds, together_seconds, own_seconds): rank 0's solo duration (broadcast to every rank), the MAX over the
+    ranks of the joint run, and this rank's own duration in the joint run.  Tensors for the collectives live on
+    `device` ("cuda:<n>" under RCCL, "cpu" under gloo)."""
+    import torch
+    import torch.distributed as dist
+    solo = torch.zeros(1, dtype=torch.float64, device=device)
+    if world > 1:
+        dist.barrier(group=group)
+    if rank == 0:
+        solo[0] = float((alone or timed)())
+    if world > 1:
+        dist.barrier(group=group)             # the others have waited here while rank 0 ran alone
+        dist.broadcast(solo, src=_global_rank(group, 0), group=group)
+        dist.barrier(group=group)             # everyone starts the joint run from here
+    own = float(timed())
+    together = torch.tensor([own], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(together, op=dist.ReduceOp.MAX, group=group)
+    return float(solo.item()), float(together.item()), own
+
+
+def _global_rank(group, group_rank: int) -> int:
+    import torch.distributed as dist
+    return dist.get_global_rank(group, group_rank) if group is not None else group_rank
+
+
 def gather_bands(local_band, bands, rank: int, dst: int = 0, group=None):
     """One-shot form of the exchange for a single frame: sends the per-rank BGRA8 bands ((h_r, w, 4) uint8 torch tensors
     on the rank's device) to `dst` and returns the assembled (H, W, 4) frame there (None elsewhere)."""
