@@ -496,6 +496,7 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
         for (uint32_t q0 = 0; q0 < n_q; q0 += 256u) {   // (the same number of turns for every work-item: the ballot below is reached by all)
             const uint32_t q = q0 + tid;
             bool drawn = false;
+            uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;   // blocks of flags the drawn triangle's box reaches into
             if (q < n_q) {
                 const uint32_t t = s_q_tri[qb][q], j0 = s_q_i0[qb][q], j1 = s_q_i1[qb][q], j2 = s_q_i2[qb][q];
                 const int2 a0 = plane_at(xy, j0), a1 = plane_at(xy, j1), a2 = plane_at(xy, j2);
@@ -504,18 +505,17 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
                 sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
                 const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
                 drawn = micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_view, g);
-                if (drawn) {
-                    // every block the box reaches into may hold something now.  One block as a rule; a box of up to micro_pixels
-                    // pixels can be a sliver one pixel wide and 32 rows tall (five rows of blocks) or the transpose (two columns).
-                    static_assert(micro_pixels<S>() <= (int)kFlagBlockW, "a micro-triangle's box spans two block columns at most");
-                    const uint32_t bx0 = (uint32_t)(x0 - g.rx) / kFlagBlockW, bx1 = (uint32_t)(x0 + npx - 1 - g.rx) / kFlagBlockW;
-                    const uint32_t by0 = (uint32_t)(y0 - g.ry) / kFlagBlockH, by1 = (uint32_t)(y0 + npy - 1 - g.ry) / kFlagBlockH;
-                    for (uint32_t by = by0; by <= by1; ++by) {
-                        flags.at(view0 + view, bx0, by) = 1u;
-                        if (bx1 != bx0) flags.at(view0 + view, bx1, by) = 1u;
-                    }
-                }
+                // every block the box reaches into may hold something now.  One block as a rule; a box of up to micro_pixels
+                // pixels can be a sliver one pixel wide and 32 rows tall (five rows of blocks) or the transpose (two columns).
+                static_assert(micro_pixels<S>() <= (int)kFlagBlockW, "a micro-triangle's box spans two block columns at most");
+                bx0 = (uint32_t)(x0 - g.rx) / kFlagBlockW; bx1 = (uint32_t)(x0 + npx - 1 - g.rx) / kFlagBlockW;
+                by0 = (uint32_t)(y0 - g.ry) / kFlagBlockH; by1 = (uint32_t)(y0 + npy - 1 - g.ry) / kFlagBlockH;
             }
+            if (drawn)
+                for (uint32_t by = by0; by <= by1; ++by) {
+                    flags.at(view0 + view, bx0, by) = 1u;
+                    if (bx1 != bx0) flags.at(view0 + view, bx1, by) = 1u;
+                }
             n_micro += (uint32_t)__popcll(__ballot(drawn));   // of the wave
         }
     }
