@@ -89,6 +89,9 @@ typedef struct sr_draw_counts {
     uint64_t lean_draws;          /* of them, issued lean */
     uint64_t lean_redraws;        /* lean draws that had to be issued again in full */
     uint64_t overflow_redraws;    /* draws issued again because the tile reference list was too small */
+    uint64_t chunks_tested;       /* one-view draws into a target restricted to a rectangle test every chunk of 768 consecutive triangles */
+    uint64_t chunks_culled;       /* against the rectangle: chunks (and the vertices only they use) that were skipped because no */
+                                  /* triangle of theirs can touch a stored pixel.  The frame is the same with and without. */
 } sr_draw_counts;
 
 /* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */
@@ -224,8 +227,8 @@ SR_API int sr_device_set_normal_mapping(sr_device dev, int enabled);
 
 /* ---- instrumentation (no reference counterpart) */
 SR_API int sr_draw_get_stats(sr_device dev, sr_target target, sr_draw_stats* out);
-/* Instrumentation, no reference counterpart: see sr_draw_counts.  Does not wait for anything; draws still in flight
- * that turn out to need a second issue are counted when they are resolved (read-back, stats, synchronize). */
+/* Instrumentation, no reference counterpart: see sr_draw_counts.  Waits for the device's stream (the culling counters live in
+ * device memory); draws that turn out to need a second issue are counted when they are resolved (read-back, stats, synchronize). */
 SR_API int sr_device_get_draw_counts(sr_device dev, sr_draw_counts* out);
 /* When enabled, sr_draw brackets every stage with HIP events on the device's stream. */
 SR_API int sr_profile_enable(sr_device dev, int enabled);

@@ -36,11 +36,20 @@
  *   - 8 sub-pixel bits, round-to-nearest-even snapping, 64-bit integer edge functions,
  *     top-left fill rule, pixel centre at +0.5, Vulkan standard 4x sample positions.
  *   - depth at a sample = l0*z0 + l1*z1 + l2*z2 with l_i = float(E_i) * (1/float(2A)).
- *   - a triangle with a vertex at w <= 0 or outside a 2^20-pixel guard band is dropped and
- *     counted -- or, with sro_set_near_clip(1), clipped against the near plane (see near_clip_polygon);
- *     fragments with depth outside [0,1] are dropped (clip volume, no depth clamp).
- *   - texture LOD from coarse 2x2-quad differences, isotropic (the sampler's 16x anisotropy
- *     is recorded but the footprint is implementation-defined; not applied here).
+ *   - a triangle with one or two vertices at w <= 0 or outside a 2^20-pixel guard band is clipped, as the
+ *     reference's fixed-function clipper does (depthClampEnable = VK_FALSE, src/main.cpp:586): cut at the near
+ *     plane and at four side planes inside the guard band, the pieces drawn as a fan under the triangle's own
+ *     id (near_clip_polygon).  sro_set_near_clip(1) selects this; the checker's callers always do.  With
+ *     sro_set_near_clip(0) such a triangle is dropped and counted instead -- the behaviour of a library
+ *     whose clip list is full, kept so that case can be checked too.  A triangle with all three vertices
+ *     unprojectable draws nothing either way.  Fragments with depth outside [0,1) are dropped (clip volume,
+ *     no depth clamp; 1.0 never passes LESS against the cleared 1.0).
+ *   - texture LOD from coarse 2x2-quad differences.  The sampler's maxAnisotropy (src/texture.cpp:255-256:
+ *     16) is applied by the method the Vulkan specification spells out when sro_set_anisotropic(1) is set:
+ *     eta = min(rho_max / rho_min, maxAniso), N = ceil(eta) trilinear taps at i/(N+1) - 1/2 along the major
+ *     axis' derivative, lambda = log2(rho_max / eta).  With sro_set_anisotropic(0) the footprint is the
+ *     isotropic one (a sampler with maxAnisotropy 1).  The footprint is implementation-defined in the
+ *     specification, so what a particular driver does stays unpinned either way.
  *   - sRGB encode to 8 bits is defined by 255 thresholds (decode of the half-way codes).
  *   - multisample resolve decodes the stored 8-bit samples, averages, re-encodes.
  */

@@ -85,7 +85,7 @@ def test_huge_triangles_cover_many_tiles(sr, oracle, device, anisotropic):
     _check_view(got, ref)
 
 
-def test_near_plane_crossing_is_clipped(sr, oracle, device):
+def test_near_plane_crossing_is_clipped(sr, oracle, device, anisotropic):
     """depthClampEnable = VK_FALSE (src/main.cpp:586): a quad that reaches behind the eye is cut at the near plane and
     its visible part drawn, not dropped."""
     verts, idx = sr.scene.screen_quad(z=0.0, half=500.0)   # reaches behind the eye
@@ -155,7 +155,7 @@ def _window_triangles(sr, W, H, tris):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
-def test_tall_and_wide_slivers_then_another_scene_in_the_same_target(sr, oracle, device, samples):
+def test_tall_and_wide_slivers_then_another_scene_in_the_same_target(sr, oracle, device, samples, anisotropic):
     """Triangles one pixel wide and a few dozen rows tall (and the transpose) are resolved by the set-up kernel itself; their
     boxes reach over several of the 32 x 8-pixel blocks the shading pass and the next draw's clear go by.  Every block must be
     shaded in this draw and cleared by the next one: a second, unrelated scene (a large triangle BEHIND where the slivers were)
@@ -210,7 +210,7 @@ def test_empty_mesh_and_offscreen_mesh(sr, oracle, device):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
-def test_target_is_reused_across_different_draws(sr, oracle, device, samples):
+def test_target_is_reused_across_different_draws(sr, oracle, device, samples, anisotropic):
     """One target, a sequence of unrelated draws: nothing of an earlier frame may survive into a later
     one.  Sphere in two views -> nothing in view 0 only -> a small soup in both views -> the sphere again
     from another camera in view 0 only; every frame is checked against the oracle."""
@@ -317,7 +317,7 @@ def test_a_block_of_fuzz_cases(sr, oracle, device):
     assert lowest >= 0.999
 
 
-def test_lean_draws_and_their_fallback(sr, oracle):
+def test_lean_draws_and_their_fallback(sr, oracle, anisotropic):
     """A draw that follows one which left nothing for the tile lists and the clipper is issued without those kernels;
     if it turns out to need them after all, it is issued again in full before anything of it can be observed.  One
     target, one mesh, a camera that jumps: far (micro-triangles only) twice, close (triangles of a dozen pixels), far
@@ -439,7 +439,7 @@ def _inward_sphere(sr, x_segments, y_segments, radius):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
-def test_near_plane_clipper(sr, oracle, samples):
+def test_near_plane_clipper(sr, oracle, samples, anisotropic):
     """Triangles with a vertex behind the eye are cut at the near plane and drawn, as the fixed-function clipper of
     the reference's pipeline does (depthClampEnable = VK_FALSE, src/main.cpp:586).  A ground
     quad that passes under and behind the camera, and a sphere seen from inside with the eye close to its surface
@@ -649,6 +649,47 @@ def test_screen_split_is_partition_independent(sr, oracle, device, samples):
             assert np.array_equal(part[key], full[key][y:y + h, x:x + w]), f"{key} differs in rect {rect}"
         ref = oracle.draw(ubo, verts, idx, images, 640, 480, samples, rect=rect, threads=4)
         _check_view(part, ref)
+
+
+def test_chunks_outside_a_band_are_skipped_and_the_band_stays_the_same(sr, oracle):
+    """A one-view draw into a target restricted to a rectangle (a band of a frame split over several GPUs) tests every chunk of 768
+    consecutive triangles against the rectangle and skips the chunks -- and the vertices only they use -- that cannot touch it.
+    Bands and odd rectangles of four scenes (a sphere under the default camera; the same under a rotating, scaling, mirroring model
+    matrix; the eye inside a large sphere, where chunks reach behind the eye and must be kept; a soup whose shuffled triangle order
+    makes every chunk refer to vertices all over the mesh) are bit-identical to the same draw without culling and to the oracle's
+    rectangle; chunks are in fact culled; a whole frame drawn through the same device afterwards is untouched by it."""
+    W, H = 480, 360
+    rng = np.random.default_rng(9)
+    sphere = sr.scene.uv_sphere(240, 160)                       # 76 800 triangles: 100 chunks
+    big = _inward_sphere(sr, 200, 150, 3.0)
+    soup_v, soup_i = util.random_soup(9000, 4, size=0.3)
+    soup_i = soup_i.reshape(-1, 3)[rng.permutation(9000)].reshape(-1).astype(np.uint32)
+    images = sr.scene.material_textures(64, seed=1)
+    scenes = [(sphere, sr.scene.default_camera_ubo(W, H)), (sphere, _random_view(np.random.default_rng(5), W, H, sr)),
+              (big, sr.scene.default_camera_ubo(W, H, eye=(0.4, 0.3, 0.2))), ((soup_v, soup_i), sr.scene.default_camera_ubo(W, H))]
+    rects = [(0, 0, W, 90), (0, 90, W, 90), (0, 180, W, 64), (0, 244, W, 116), (130, 77, 201, 55), (0, 0, 31, H), (400, 300, 80, 60)]
+    culling, plain = util.device_with_env(sr, SR_CULL_MIN_CHUNKS="1"), util.device_with_env(sr, SR_NO_CULL="1")
+    try:
+        for k, ((verts, idx), ubo) in enumerate(scenes):
+            before = culling.draw_counts()
+            for rect in rects:
+                a = util.gpu_render(sr, culling, verts, idx, images, ubo, W, H, 1, rect=rect)[0]
+                b = util.gpu_render(sr, plain, verts, idx, images, ubo, W, H, 1, rect=rect)[0]
+                assert np.array_equal(a["vis"], b["vis"]) and np.array_equal(a["bgra"], b["bgra"]), (k, rect)
+                assert {x: y for x, y in a["stats"].items() if x != "passes"} == {x: y for x, y in b["stats"].items() if x != "passes"}, (k, rect)
+                _check_view(a, oracle.draw(ubo, verts, idx, images, W, H, 1, rect=rect, threads=4))
+            after = culling.draw_counts()
+            tested, culled = after["chunks_tested"] - before["chunks_tested"], after["chunks_culled"] - before["chunks_culled"]
+            chunks = -(-(idx.size // 3) // 768)
+            assert tested >= len(rects) * chunks, (k, tested)       # (every draw of a rectangle was tested; a redrawn one twice)
+            if k in (0, 1):
+                assert culled > tested // 3, (k, tested, culled)    # a band holds a fraction of the sphere
+            whole = util.gpu_render(sr, culling, verts, idx, images, ubo, W, H, 1)[0]
+            assert culling.draw_counts()["chunks_tested"] == after["chunks_tested"]     # the whole frame is not culled
+            _check_view(whole, oracle.draw(ubo, verts, idx, images, W, H, 1, threads=4))
+        assert plain.draw_counts()["chunks_tested"] == 0
+    finally:
+        culling.close(); plain.close()
 
 
 def test_non_power_of_two_and_mixed_size_textures(sr, oracle, device, anisotropic):

@@ -89,6 +89,13 @@ struct sr_device_t {
     std::vector<sr_target_t*> targets;   // live targets of this device (they may hold a reference to a mesh and textures)
     void* static_scratch = nullptr;      // this GPU's copy of the array `scratch` (sr_api.hip), looked up at creation
     sr_draw_counts counts{};             // sr_device_get_draw_counts
+    // chunk culling (sr_device.h): per-draw flags, allocated on first use; the stamps compare against an epoch that goes up with
+    // every culled draw, so they never need clearing
+    DeviceBuffer cull_visible, cull_stamp;
+    unsigned long long* d_cull_counts = nullptr;   // [2] chunks tested / culled, cumulative
+    uint32_t cull_epoch = 0;
+    uint32_t cull_min_chunks = 8;                  // meshes of fewer chunks are not worth the extra launch (SR_CULL_MIN_CHUNKS)
+    bool cull_enabled = true;                      // SR_NO_CULL=1 turns it off
 };
 
 struct sr_mesh_t {
@@ -96,6 +103,9 @@ struct sr_mesh_t {
     float *px = nullptr, *py = nullptr, *pz = nullptr;
     uint32_t* d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
+    float4* d_chunk_sphere = nullptr;   // chunk culling: bounds of every chunk of setup_block_triangles() triangles ([chunks] spheres, then
+    uint2* d_chunk_vrange = nullptr;    // [chunks] vertex ranges in the same allocation)
+    uint32_t n_chunks = 0;
 };
 
 struct sr_texture_t {
@@ -148,6 +158,30 @@ double srgb_decode_d(double x) { return x <= 0.04045 ? x / 12.92 : std::pow((x +
 void mat4_mul_mat4_host(const float* A, const float* B, float* R)
 {
     for (int c = 0; c < 4; ++c) mat4_mul_vec4(A, B[4 * c], B[4 * c + 1], B[4 * c + 2], B[4 * c + 3], R + 4 * c);
+}
+
+// rows x, y, w of proj * view * model in double precision, rounded once (chunk culling, sr_device.h)
+CullView make_cull_view(const ViewXform& x)
+{
+    CullView v{};
+    const int rows[3] = {0, 1, 3};
+    float* out[3] = {v.ax, v.ay, v.aw};
+    float* norm[3] = {&v.nx, &v.ny, &v.nw};
+    double scale = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        double a[4], n2 = 0.0;
+        for (int c = 0; c < 4; ++c) {
+            a[c] = 0.0;
+            for (int j = 0; j < 4; ++j) a[c] += (double)x.pv[4 * j + rows[k]] * (double)x.model[4 * c + j];   // column-major: element (r, c) at [4 * c + r]
+            out[k][c] = (float)a[c];
+            scale += std::fabs(a[c]);
+            for (int j = 0; j < 4; ++j) scale += std::fabs((double)x.pv[4 * j + rows[k]] * (double)x.model[4 * c + j]) * 0.25;   // (the terms' sizes, not only their sum's)
+        }
+        for (int c = 0; c < 3; ++c) n2 += a[c] * a[c];
+        *norm[k] = (float)(std::sqrt(n2) * 1.000001);
+    }
+    v.scale = (float)scale;
+    return v;
 }
 
 TexDesc make_tex_desc(const sr_texture_t* t)
@@ -322,6 +356,27 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     const sr_texture_t* metallic = tg->tex[2];
     const sr_texture_t* roughness = tg->tex[3];
 
+    // Chunk culling: a one-view draw into a target restricted to a rectangle (a band of a frame split over several GPUs).  One small
+    // launch decides which chunks of the mesh can touch the rectangle; the vertex stage then skips the groups of vertices no such
+    // chunk uses and set-up's workgroups for the other chunks leave at once.
+    CullUse cull_use{nullptr, nullptr, 0u};
+    if (dev->cull_enabled && !no_alloc && n_views == 1 && views_by_argument && m->n_verts && m->d_chunk_sphere && m->n_chunks >= dev->cull_min_chunks &&
+        (g.rw < g.W || g.rh < g.H)) {
+        const size_t stamp_words = 1 + (size_t)(v_stride + kCullVertexGroup - 1) / kCullVertexGroup;
+        const size_t had = dev->cull_stamp.bytes;
+        SR_HIP(dev->cull_visible.ensure((size_t)m->n_chunks * 4));
+        SR_HIP(dev->cull_stamp.ensure(stamp_words * 4));
+        if (dev->cull_stamp.bytes != had || dev->cull_epoch == 0xFFFFFFFFu) {   // new memory (or the epoch about to wrap): no stamp may equal a coming epoch
+            SR_HIP(hipMemsetAsync(dev->cull_stamp.ptr, 0, dev->cull_stamp.bytes, st));
+            dev->cull_epoch = 0;
+        }
+        ChunkCull cc{};
+        cc.sphere = m->d_chunk_sphere; cc.vrange = m->d_chunk_vrange; cc.n_chunks = m->n_chunks;
+        cc.visible = (uint32_t*)dev->cull_visible.ptr; cc.stamp = (uint32_t*)dev->cull_stamp.ptr; cc.epoch = ++dev->cull_epoch; cc.counts = dev->d_cull_counts;
+        launch_chunk_cull(st, cc, make_cull_view(tg->views[0]), g);
+        cull_use = CullUse{cc.visible, cc.stamp, cc.epoch};
+    }
+
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const uint32_t v0 = pass * vpp, nv = std::min(vpp, n_views - v0);
         const ViewXform* d_views = ps.views + v0;
@@ -330,7 +385,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         // one launch starts the pass and runs the vertex stage when the transforms fit its arguments (then n_views == nv: one pass)
         const bool fused = views_by_argument &&
                            launch_vertex_and_begin(st, m->px, m->py, m->pz, m->n_verts, tg->views.data() + v0, nv, ps.views + v0, g.W, g.H, sp, tg->d_vis, tg->flags, g, v0,
-                                                   b.count_small, zero_words * 4);
+                                                   b.count_small, zero_words * 4, cull_use);
         if (!fused) {
             const bool copy_views = pass == 0 && staging && !views_by_argument;
             launch_begin_pass(st, tg->d_vis, tg->flags, g, v0, nv, b.count_small, zero_words * 4, copy_views ? staging->d : nullptr, ps.views,
@@ -340,7 +395,8 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr, dev->fill_blocks);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
-        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, tg->flags, v0, ev ? ev[3] : nullptr, !tg->lean, dev->fill_blocks);
+        launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, tg->flags, v0, ev ? ev[3] : nullptr, !tg->lean, dev->fill_blocks,
+                     fused ? cull_use.visible : nullptr);   // (culled vertex groups were skipped by the fused vertex launch only)
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
@@ -477,12 +533,17 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     // this GPU's copy of the static scratch array (the device is current: hipSetDevice above)
     if (e == hipSuccess) e = hipGetSymbolAddress(&dev->static_scratch, HIP_SYMBOL(scratch));
     if (e == hipSuccess && dev->static_scratch == nullptr) e = hipErrorInvalidSymbol;
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->d_cull_counts, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(dev->d_cull_counts, 0, 16, dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) { (void)sr_device_destroy(dev); SR_HIP(e); }
     if (const char* v = std::getenv("SR_TILE_LOG2")) dev->tile_log2_override = std::atoi(v);
     if (const char* v = std::getenv("SR_SCRATCH_GIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 30;
     if (const char* v = std::getenv("SR_REF_CAPACITY")) dev->ref_capacity = (uint64_t)std::max(1, std::atoi(v));   // initial size of the tile reference list (tests: force the grow-and-redraw path)
     if (const char* v = std::getenv("SR_CLIP_CAPACITY")) dev->clip_capacity = (uint32_t)std::max(1, std::atoi(v));   // tests: a full clip list
     if (const char* v = std::getenv("SR_FILL_BLOCKS")) dev->fill_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = a workgroup always takes all views
+    if (const char* v = std::getenv("SR_CULL_MIN_CHUNKS")) dev->cull_min_chunks = (uint32_t)std::max(1, std::atoi(v));   // tests: cull small meshes too
+    if (std::getenv("SR_NO_CULL")) dev->cull_enabled = false;
     if (const char* v = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 20;   // small budgets: many passes per draw
     *out = dev;
     return SR_OK;
@@ -496,6 +557,7 @@ int sr_device_destroy(sr_device dev)
     for (hipEvent_t e : dev->events) (void)hipEventDestroy(e);
     dev->screen.release(); dev->tile_count.release(); dev->tile_offset.release(); dev->records.release();
     dev->pending.release(); dev->refs.release(); dev->views.release(); dev->clip.release();
+    dev->cull_visible.release(); dev->cull_stamp.release(); (void)hipFree(dev->d_cull_counts);
     for (auto& sg : dev->staging) { if (sg.h) (void)hipHostFree(sg.h); if (sg.ev) (void)hipEventDestroy(sg.ev); }
     (void)hipFree(dev->d_decode); (void)hipFree(dev->d_thresh);
     if (dev->stream) (void)hipStreamDestroy(dev->stream);
@@ -541,6 +603,14 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
     if (n_vertices) e = hipMemcpyAsync(m->d_aos, vertices, (size_t)n_vertices * 32, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess && n_tris) e = hipMemcpyAsync(m->d_idx, indices, (size_t)n_tris * 12, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
+    if (e == hipSuccess && n_tris) {   // bounds of every chunk, for draws into a restricted rectangle
+        m->n_chunks = (n_tris + setup_block_triangles() - 1) / setup_block_triangles();
+        e = hipMalloc((void**)&m->d_chunk_sphere, (size_t)m->n_chunks * (sizeof(float4) + sizeof(uint2)));
+        if (e == hipSuccess) {
+            m->d_chunk_vrange = (uint2*)(m->d_chunk_sphere + m->n_chunks);
+            launch_chunk_bounds(dev->stream, m->d_idx, n_tris, m->d_aos, m->d_chunk_sphere, m->d_chunk_vrange);
+        }
+    }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);   // uploaded on return, like the reference's blocking staging copy
     if (e != hipSuccess) { (void)sr_mesh_destroy(dev, m); SR_HIP(e); }
@@ -556,7 +626,7 @@ int sr_mesh_destroy(sr_device dev, sr_mesh mesh)
         release_references(dev, mesh, nullptr);
         (void)hipStreamSynchronize(dev->stream);
     }
-    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx);
+    (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx); (void)hipFree(mesh->d_chunk_sphere);
     delete mesh;
     return SR_OK;
 }
@@ -932,6 +1002,11 @@ int sr_device_get_draw_counts(sr_device dev, sr_draw_counts* out)
 {
     if (!dev || !out) return fail(SR_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = dev->counts;
+    unsigned long long c[2] = {0, 0};
+    SR_HIP(hipSetDevice(dev->ordinal));
+    SR_HIP(hipStreamSynchronize(dev->stream));     // (the two culling counters live in device memory)
+    SR_HIP(hipMemcpy(c, dev->d_cull_counts, sizeof c, hipMemcpyDeviceToHost));
+    out->chunks_tested = c[0]; out->chunks_culled = c[1];
     return SR_OK;
 }
 

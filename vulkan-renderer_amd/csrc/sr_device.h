@@ -206,6 +206,37 @@ __device__ inline bool depth_key(const TriSetup& t, int64_t Ea, int64_t Eb, int6
     return true;
 }
 
+// Culling of whole chunks of the mesh against the stored rectangle (draws of one view into a target restricted to a
+// rectangle: the bands of a frame split over several GPUs).  A chunk is the kChunkCullTris consecutive triangles one set-up
+// workgroup handles; at mesh creation every chunk gets a bounding sphere of the positions it references and the range of vertex
+// numbers it uses.  Per draw, one small kernel projects the spheres conservatively: a chunk whose every vertex provably lands
+// outside the rectangle (by more than the slack below) cannot touch a stored pixel, its set-up workgroup leaves at once, and the
+// groups of kCullVertexGroup vertices no surviving chunk refers to are not transformed.  Nothing else changes: what is drawn is
+// computed exactly as without culling, so a band stays bit-identical to the same rows of the whole frame.
+constexpr uint32_t kCullVertexGroup = 256;        // vertices per flag of the vertex stage: one wave of the fused vertex kernel
+constexpr uint32_t kCullMaxGroupsPerChunk = 64;   // a chunk whose vertex numbers span more groups marks "every vertex" instead
+constexpr float kCullSlackPixels = 2.0f;          // on every side of the projected bound
+struct CullView {            // rows x, y, w of (proj * view * model), their 3-vectors' lengths, made on the host in double precision
+    float ax[4], ay[4], aw[4];
+    float nx, ny, nw;
+    float scale;             // |entries| of the rows summed: the rounding allowance of the device's own float evaluation is a multiple of it
+};
+struct ChunkCull {
+    const float4* sphere;    // [chunks]: centre, radius (infinite when a position is not finite)
+    const uint2* vrange;     // [chunks]: lowest and highest vertex number the chunk's triangles use
+    uint32_t n_chunks;
+    uint32_t* visible;       // [chunks], written per draw: 0 = the chunk cannot touch the stored rectangle
+    uint32_t* stamp;         // [1 + vertex groups]: == epoch when the group (word 0: every group) must be transformed in this draw
+    uint32_t epoch;
+    unsigned long long* counts;   // [2], cumulative: chunks tested, chunks culled
+};
+// what the vertex and set-up kernels get (null pointers: no culling)
+struct CullUse {
+    const uint32_t* visible;
+    const uint32_t* stamp;
+    uint32_t epoch;
+};
+
 // binning records ---------------------------------------------------------------------------------
 struct BinRecord {            // 12 bytes, written by set-up, read by fill
     uint32_t tri;             // triangle id

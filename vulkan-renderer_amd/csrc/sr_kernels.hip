@@ -139,7 +139,7 @@ __device__ inline void vertex_group(const Views& views, uint32_t view_begin, uin
 // is one launch shorter.  Everything it writes is first read by the kernels that follow.
 __global__ __launch_bounds__(256) void vertex_begin_kernel(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
                                                            uint32_t n, ViewPack pack, ViewXform* __restrict__ views_dst, int W, int H,
-                                                           ScreenPlanes out, BeginWork w)
+                                                           ScreenPlanes out, BeginWork w, CullUse cull)
 {
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x, gstride = (size_t)gridDim.x * 256u;
     if (blockIdx.x == 0) {
@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256) void vertex_begin_kernel(const float* __restri
         for (uint32_t i = threadIdx.x; i < w.n_views * kWords; i += 256u) reinterpret_cast<uint32_t*>(views_dst)[i] = src[i];
     }
     begin_work(w, gtid, gstride);
-    vertex_group<kFusedVertexGroup>(pack.v, 0u, w.n_views, px, py, pz, n, blockIdx.x * 256u + threadIdx.x, W, H, out, nullptr, nullptr);
+    const uint32_t group = blockIdx.x * 256u + threadIdx.x;
+    // chunk culling (a one-view draw into a restricted rectangle): a wave's kCullVertexGroup vertices are transformed only if a chunk
+    // that can touch the rectangle refers to the group -- the same answer for the whole wave
+    static_assert(kCullVertexGroup == 64u * kFusedVertexGroup, "one flag per wave of this kernel");
+    if (cull.stamp && kFusedVertexGroup * group < n && cull.stamp[0] != cull.epoch && cull.stamp[1u + group / 64u] != cull.epoch) return;
+    vertex_group<kFusedVertexGroup>(pack.v, 0u, w.n_views, px, py, pz, n, group, W, H, out, nullptr, nullptr);
 }
 
 __global__ __launch_bounds__(256) void vertex_kernel(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
@@ -369,7 +374,7 @@ __device__ inline T plane_at(const T* plane, uint32_t byte_offset)
 template <int S, bool VIEW_LOOP>
 __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                     FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, BlockFlags flags,
-                                                    uint32_t view0, uint32_t n_views, uint32_t views_per_block)
+                                                    uint32_t view0, uint32_t n_views, uint32_t views_per_block, const uint32_t* __restrict__ chunk_visible)
 {
     // One barrier per view, between the two phases.  A wave that is through with a view goes on to the next while others still walk
     // the queue, so the queue exists twice (views alternate) and its counter three times: the counter of the next view is zeroed at the
@@ -381,6 +386,9 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     const uint32_t turn = xcd_runs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const uint32_t blk = turn % gridDim.x, view_begin = turn / gridDim.x * views_per_block;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    // chunk culling (one-view draws into a restricted rectangle only, so never with the view loop): none of the workgroup's triangles
+    // can touch a stored pixel -- and their vertices may not even have been transformed
+    if (!VIEW_LOOP && chunk_visible && chunk_visible[blk] == 0u) return;   // (the same for the whole workgroup, before any barrier)
     // i0, i1, i2: the three vertices of a triangle as BYTE offsets into a view's xy plane (index * 8; half of it is the offset into the
     // z plane).  A plane holds fewer than 2^29 vertices (checked when the mesh is made), so the offsets fit 32 bits and every gather is
     // a plane's base address, the same for the whole wave, plus a 32-bit offset per lane: no 64-bit address arithmetic per view.
@@ -1680,6 +1688,121 @@ __global__ __launch_bounds__(256) void mip_blit_kernel(const uint32_t* __restric
 }
 
 // =================================================================================================
+// chunk culling (sr_device.h): bounds per chunk at mesh creation, one projection test per chunk and draw
+// =================================================================================================
+constexpr uint32_t kChunkCullTris = kSetupBlockTris;   // a chunk is what one set-up workgroup handles
+__device__ inline float block_reduce(float v, bool take_max, float* s_tmp /* 4 floats */, uint32_t tid)
+{
+    for (int o = 32; o > 0; o >>= 1) { const float u = __shfl_down(v, o); v = take_max ? fmaxf(v, u) : fminf(v, u); }   // lane 0 ends up with the wave's
+    __syncthreads();   // s_tmp's last readers are through
+    if ((tid & 63u) == 0u) s_tmp[tid >> 6] = v;
+    __syncthreads();
+    const float a = s_tmp[0], b = s_tmp[1], c = s_tmp[2], d = s_tmp[3];
+    return take_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : fminf(fminf(a, b), fminf(c, d));
+}
+// One workgroup per chunk: bounding sphere (centre of the bounding box, largest distance of a referenced position from it, a few ulp
+// added) and the range of vertex numbers.  A position that is not finite makes the radius infinite: such a chunk is never culled.
+__global__ __launch_bounds__(256) void chunk_bounds_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, const float4* __restrict__ verts /* 2 float4 per vertex */,
+                                                           float4* __restrict__ sphere, uint2* __restrict__ vrange)
+{
+    __shared__ float s_tmp[4];
+    __shared__ uint32_t s_lo, s_hi;
+    const uint32_t tid = threadIdx.x, first = blockIdx.x * kChunkCullTris;
+    if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
+    float p[3 * kSetupTris][3];
+    bool have[kSetupTris];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    uint32_t vlo = 0xFFFFFFFFu, vhi = 0u;
+    bool finite = true;
+#pragma unroll
+    for (uint32_t k = 0; k < kSetupTris; ++k) {
+        const uint32_t t = first + k * 256u + tid;
+        have[k] = t < n_tris;
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c) {
+            const uint32_t i = have[k] ? idx[3 * (size_t)t + c] : 0u;
+            const float4 a = have[k] ? verts[2 * (size_t)i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            p[3 * k + c][0] = a.x; p[3 * k + c][1] = a.y; p[3 * k + c][2] = a.z;
+            if (have[k]) {
+                vlo = min(vlo, i); vhi = max(vhi, i);
+                finite = finite && fabsf(a.x) <= 3.0e38f && fabsf(a.y) <= 3.0e38f && fabsf(a.z) <= 3.0e38f;   // (false for infinities and NaNs)
+                lo[0] = fminf(lo[0], a.x); lo[1] = fminf(lo[1], a.y); lo[2] = fminf(lo[2], a.z);
+                hi[0] = fmaxf(hi[0], a.x); hi[1] = fmaxf(hi[1], a.y); hi[2] = fmaxf(hi[2], a.z);
+            }
+        }
+    }
+    float centre[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float l = block_reduce(lo[c], false, s_tmp, tid), h = block_reduce(hi[c], true, s_tmp, tid);
+        centre[c] = 0.5f * l + 0.5f * h;
+    }
+    float r2 = 0.0f;
+#pragma unroll
+    for (uint32_t k = 0; k < kSetupTris; ++k)
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c)
+            if (have[k]) {
+                const float dx = p[3 * k + c][0] - centre[0], dy = p[3 * k + c][1] - centre[1], dz = p[3 * k + c][2] - centre[2];
+                r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+            }
+    r2 = block_reduce(r2, true, s_tmp, tid);
+    const float all_finite = block_reduce(finite ? 1.0f : 0.0f, false, s_tmp, tid);
+    atomicMin(&s_lo, vlo); atomicMax(&s_hi, vhi);
+    __syncthreads();
+    if (tid == 0) {
+        float r = sqrtf(r2) * 1.00001f + 1.0e-30f;            // (rounding of the squares and the root: a few ulp; this adds a thousand)
+        if (!(all_finite > 0.5f) || !(r <= 3.0e38f)) r = __builtin_inff();
+        sphere[blockIdx.x] = make_float4(centre[0], centre[1], centre[2], r);
+        vrange[blockIdx.x] = make_uint2(s_lo, s_hi);
+    }
+}
+
+// One work-item per chunk.  With A = proj * view * model, every position p of the chunk has clip coordinate
+// A_r . (c, 1) + A_r[0..2] . (p - c), the second term at most radius * |A_r[0..2]| in size.  If w stays positive over the sphere,
+// x / w and y / w over it are bounded by the quotients of the ends, and the chunk's window coordinates by the viewport transform of
+// those; slack: kCullSlackPixels plus the rounding the device's own float evaluation of a vertex can differ by.  Anything not
+// provably outside stays (comparisons with a NaN are false).
+__global__ __launch_bounds__(256) void chunk_cull_kernel(ChunkCull cc, CullView v, FrameGeom g)
+{
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
+    bool culled = false;
+    if (chunk < cc.n_chunks) {
+        const float4 s = cc.sphere[chunk];
+        const float reach = fabsf(s.x) + fabsf(s.y) + fabsf(s.z) + s.w + 1.0f;
+        const float round_off = 1.0e-5f * v.scale * reach;          // (the device's clip coordinates carry a few ulp of the terms' sizes: 1e-7 of them)
+        const float cx = fmaf(v.ax[2], s.z, fmaf(v.ax[1], s.y, fmaf(v.ax[0], s.x, v.ax[3])));
+        const float cy = fmaf(v.ay[2], s.z, fmaf(v.ay[1], s.y, fmaf(v.ay[0], s.x, v.ay[3])));
+        const float cw = fmaf(v.aw[2], s.z, fmaf(v.aw[1], s.y, fmaf(v.aw[0], s.x, v.aw[3])));
+        const float ex = s.w * v.nx * 1.0001f + round_off, ey = s.w * v.ny * 1.0001f + round_off, ew = s.w * v.nw * 1.0001f + round_off;
+        const float w_lo = cw - ew, w_hi = cw + ew;
+        if (w_lo > 1.0e-6f * (fabsf(cw) + ew) && w_lo > 0.0f) {     // every vertex in front of the eye, by a margin
+            const float x_lo = cx - ex, x_hi = cx + ex, y_lo = cy - ey, y_hi = cy + ey;
+            const float ndc_x_max = fmaxf(x_hi / w_lo, x_hi / w_hi), ndc_x_min = fminf(x_lo / w_lo, x_lo / w_hi);
+            const float ndc_y_max = fmaxf(y_hi / w_lo, y_hi / w_hi), ndc_y_min = fminf(y_lo / w_lo, y_lo / w_hi);
+            const float hw = 0.5f * (float)g.W, hh = 0.5f * (float)g.H;
+            const float slack_x = kCullSlackPixels + 1.0e-5f * (float)g.W, slack_y = kCullSlackPixels + 1.0e-5f * (float)g.H;
+            const float wx_min = hw + ndc_x_min * hw - slack_x, wx_max = hw + ndc_x_max * hw + slack_x;
+            const float wy_min = hh - ndc_y_max * hh - slack_y, wy_max = hh - ndc_y_min * hh + slack_y;    // (the viewport is flipped: src/main.cpp:564-571)
+            culled = wx_max < (float)g.rx || wx_min > (float)(g.rx + g.rw) || wy_max < (float)g.ry || wy_min > (float)(g.ry + g.rh);
+        }
+        cc.visible[chunk] = culled ? 0u : 1u;
+        if (!culled) {
+            const uint2 r = cc.vrange[chunk];
+            const uint32_t g0 = r.x / kCullVertexGroup, g1 = r.y / kCullVertexGroup;
+            if (r.x > r.y) { /* a chunk without triangles refers to no vertex */ }
+            else if (g1 - g0 >= kCullMaxGroupsPerChunk) cc.stamp[0] = cc.epoch;      // scattered indices: every group (same value from every writer)
+            else for (uint32_t k = g0; k <= g1; ++k) cc.stamp[1u + k] = cc.epoch;
+        }
+    }
+    const uint64_t m = __ballot(culled), all = __ballot(chunk < cc.n_chunks);
+    if (lane_id() == 0u && all) {
+        atomicAdd(&cc.counts[0], (unsigned long long)__popcll(all));
+        if (m) atomicAdd(&cc.counts[1], (unsigned long long)__popcll(m));
+    }
+}
+
+// =================================================================================================
 // read-back helpers and work counters (not on the timed path)
 // =================================================================================================
 __global__ __launch_bounds__(256) void split_vis_kernel(const unsigned long long* __restrict__ vis, size_t n, float* __restrict__ depth, uint32_t* __restrict__ tri)
@@ -1755,7 +1878,7 @@ void launch_begin_pass(hipStream_t st, uint64_t* vis, const BlockFlags& flags, c
 
 bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* host_views, uint32_t n_views,
                              ViewXform* views_dst, int W, int H, const ScreenPlanes& out, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0,
-                             void* zero16, size_t zero_bytes)
+                             void* zero16, size_t zero_bytes, const CullUse& cull)
 {
     if (!n || !n_views || n_views > kMaxPackedViews) return false;
     ViewPack pack;
@@ -1763,7 +1886,7 @@ bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, c
     // enough workgroups for the clearing part too when the mesh is small (a workgroup past the last vertex group only clears)
     const uint32_t for_clearing = begin_blocks(flags, n_views, zero_bytes);
     vertex_begin_kernel<<<std::max(div_up(n, kFusedVertexGroup * 256u), for_clearing), 256, 0, st>>>(px, py, pz, n, pack, views_dst, W, H, out,
-                                                                       make_begin_work(vis, flags, g, view0, n_views, zero16, zero_bytes));
+                                                                       make_begin_work(vis, flags, g, view0, n_views, zero16, zero_bytes), cull);
     return true;
 }
 
@@ -1806,7 +1929,7 @@ static inline uint32_t chunk_grid(const BinBuffers& b) { return std::min<uint32_
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags, uint32_t view0, hipEvent_t between,
-                  bool bin, uint32_t fill_blocks)
+                  bool bin, uint32_t fill_blocks, const uint32_t* chunk_visible)
 {
     if (!n_tris || !n_views) return;
     // a workgroup takes every view of the pass for its triangles, unless the mesh is too small to fill the chip that way
@@ -1814,11 +1937,11 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
     const uint32_t views_per_block = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views);
     const dim3 grid(grid_x, div_up(n_views, views_per_block));
     if (views_per_block == 1) {
-        if (g.samples == 1) setup_kernel<1, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u);
-        else setup_kernel<4, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u);
+        if (g.samples == 1) setup_kernel<1, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
+        else setup_kernel<4, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
     } else {
-        if (g.samples == 1) setup_kernel<1, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block);
-        else setup_kernel<4, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block);
+        if (g.samples == 1) setup_kernel<1, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr);
+        else setup_kernel<4, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr);
     }
     if (between) (void)hipEventRecord(between, st);
     if (!bin) return;
@@ -1865,6 +1988,18 @@ void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const S
     // on the reference's own 800x600 4-sample frame)
     else if (g.samples == 4 && g.tile_log2 == 5) raster_kernel<5, 4, 512><<<grid, 512, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
     else if (g.samples == 4 && g.tile_log2 == 4) raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
+}
+
+void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint2* vrange)
+{
+    if (!n_tris) return;
+    chunk_bounds_kernel<<<div_up(n_tris, kChunkCullTris), 256, 0, st>>>(idx, n_tris, (const float4*)verts_aos, sphere, vrange);
+}
+
+void launch_chunk_cull(hipStream_t st, const ChunkCull& cc, const CullView& v, const FrameGeom& g)
+{
+    if (!cc.n_chunks) return;
+    chunk_cull_kernel<<<div_up(cc.n_chunks, 256u), 256, 0, st>>>(cc, v, g);
 }
 
 uint32_t setup_block_triangles() { return kSetupBlockTris; }

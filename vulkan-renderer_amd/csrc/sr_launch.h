@@ -41,12 +41,15 @@ void launch_begin_pass(hipStream_t st, uint64_t* vis, const BlockFlags& flags, c
 // that does not apply (no vertices, or more than kMaxPackedViews views): the caller then uses launch_begin_pass + launch_vertex.
 bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* host_views, uint32_t n_views,
                              ViewXform* views_dst, int W, int H, const ScreenPlanes& out, uint64_t* vis, const BlockFlags& flags, const FrameGeom& g, uint32_t view0,
-                             void* zero16, size_t zero_bytes);
+                             void* zero16, size_t zero_bytes, const CullUse& cull = CullUse{nullptr, nullptr, 0u});
 // triangle set-up (micro-triangles resolved, clip list and pending lists filled) followed by the binning of the pending lists
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags /* of the target */, uint32_t view0,
                   hipEvent_t between /* recorded between set-up and binning, may be null */, bool bin = true /* false: set-up only */,
-                  uint32_t fill_blocks = kFillBlocks);
+                  uint32_t fill_blocks = kFillBlocks, const uint32_t* chunk_visible = nullptr /* chunk culling: one-view draws only */);
+// chunk culling (sr_device.h): bounds of every chunk of setup_block_triangles() triangles, once per mesh; the per-draw test
+void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint2* vrange);
+void launch_chunk_cull(hipStream_t st, const ChunkCull& cc, const CullView& v, const FrameGeom& g);
 // near-plane clipping of the triangles set-up listed: cuts them and resolves the pieces into the visibility buffer.
 // Runs after launch_setup and before launch_scan (which reports the counters to the host).
 void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const float* px, const float* py, const float* pz,
