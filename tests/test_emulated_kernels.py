@@ -40,8 +40,8 @@ def build_emulation_library():
 
 
 # device-level knobs under which every frame must stay the same: the other tile size (64 x 64 at one sample, 16 x 16 at four), a tile reference list that overflows on
-# every first frame, a scratch budget that splits batches into passes
-KNOBS = [dict(SR_TILE_LOG2="6", SR_FILL_BLOCKS="1"), dict(SR_REF_CAPACITY="16"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4")]
+# every first frame, the staged resolve of set-up for small launches too, a scratch budget that splits batches into passes, chunk culling of small meshes
+KNOBS = [dict(SR_TILE_LOG2="6", SR_FILL_BLOCKS="1"), dict(SR_REF_CAPACITY="16", SR_STAGED_MIN_BLOCKS="1"), dict(SR_SCRATCH_MIB="1", SR_TILE_LOG2="4", SR_CULL_MIN_CHUNKS="1")]
 _child_runs = {}
 
 

@@ -692,6 +692,32 @@ def test_chunks_outside_a_band_are_skipped_and_the_band_stays_the_same(sr, oracl
         culling.close(); plain.close()
 
 
+def test_staged_resolve_gives_the_same_frames(sr, oracle, device):
+    """A one-sample, one-view set-up launch of thousands of workgroups resolves its micro-triangles' samples through LDS (marked per lane,
+    numbered per wave, resolved by whole waves); smaller launches resolve inside each lane's walk.  Forced on for small launches
+    (SR_STAGED_MIN_BLOCKS=1), the frames are the default path's and the oracle's: sub-pixel triangles (a wave's samples fit one round),
+    triangles of a few dozen pixels (several rounds per wave), a soup with coplanar duplicates, far-plane fragments outside the clip
+    volume, a band of a frame."""
+    staged = util.device_with_env(sr, SR_STAGED_MIN_BLOCKS="1")
+    images = sr.scene.material_textures(64, seed=3)
+    far_ubo, far_verts, far_idx = _window_triangles(sr, 96, 64, [[[3.0 + 5 * k, 2.0 + 3 * (k % 7), 1.0], [7.5 + 5 * k, 3.0 + 3 * (k % 7), 1.0], [4.0 + 5 * k, 8.0 + 3 * (k % 7), 1.0]] for k in range(17)])
+    cases = [(sr.scene.uv_sphere(300, 200), sr.scene.default_camera_ubo(320, 200), 320, 200, None),
+             (sr.scene.uv_sphere(64, 48), sr.scene.default_camera_ubo(640, 480), 640, 480, None),
+             (sr.scene.uv_sphere(88, 88), sr.scene.default_camera_ubo(800, 600), 800, 600, (0, 200, 800, 150)),
+             (util.random_soup(5000, 12, size=0.2), sr.scene.default_camera_ubo(400, 300), 400, 300, None),
+             ((far_verts, far_idx), far_ubo, 96, 64, None)]
+    try:
+        for k, ((verts, idx), ubo, W, H, rect) in enumerate(cases):
+            a = util.gpu_render(sr, staged, verts, idx, images, ubo, W, H, 1, rect=rect)[0]
+            b = util.gpu_render(sr, device, verts, idx, images, ubo, W, H, 1, rect=rect)[0]
+            assert np.array_equal(a["vis"], b["vis"]) and np.array_equal(a["bgra"], b["bgra"]), k
+            assert a["stats"] == b["stats"], k
+            assert a["stats"]["triangles_direct"] > 0, k
+            _check_view(a, oracle.draw(ubo, verts, idx, images, W, H, 1, rect=rect, threads=4))
+    finally:
+        staged.close()
+
+
 def test_non_power_of_two_and_mixed_size_textures(sr, oracle, device, anisotropic):
     rng = np.random.default_rng(2)
     images = [rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) for (w, h) in [(100, 37), (8, 8), (1, 64), (33, 5)]]

@@ -74,6 +74,7 @@ struct sr_device_t {
     DeviceBuffer clip;           // entries of the near-plane clip list: capacity x 8 bytes
     uint32_t clip_capacity = 65536;   // triangles per pass that can be clipped; more are dropped and counted
     uint32_t fill_blocks = kFillBlocks;   // see sr_launch.h
+    uint32_t staged_min_blocks = kStagedResolveMinBlocks;   // see sr_launch.h
     bool normal_mapping = false;          // sr_device_set_normal_mapping: applies to the draws issued after it
     // pinned staging for the per-view transforms: a small ring, so that back-to-back draws do not
     // wait for each other on the host
@@ -396,7 +397,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr, dev->fill_blocks);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
         launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, tg->flags, v0, ev ? ev[3] : nullptr, !tg->lean, dev->fill_blocks,
-                     fused ? cull_use.visible : nullptr);   // (culled vertex groups were skipped by the fused vertex launch only)
+                     fused ? cull_use.visible : nullptr /* (culled vertex groups were skipped by the fused vertex launch only) */, dev->staged_min_blocks);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
@@ -544,6 +545,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* v = std::getenv("SR_FILL_BLOCKS")) dev->fill_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = a workgroup always takes all views
     if (const char* v = std::getenv("SR_CULL_MIN_CHUNKS")) dev->cull_min_chunks = (uint32_t)std::max(1, std::atoi(v));   // tests: cull small meshes too
     if (std::getenv("SR_NO_CULL")) dev->cull_enabled = false;
+    if (const char* v = std::getenv("SR_STAGED_MIN_BLOCKS")) dev->staged_min_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = the staged resolve for small launches too
     if (const char* v = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 20;   // small budgets: many passes per draw
     *out = dev;
     return SR_OK;

@@ -305,6 +305,38 @@ __device__ inline bool micro_draw(const MicroEdges& e, int x0, int y0, int npx, 
     return any;
 }
 
+// The same walk without the resolve: bit n of the result is set when sample n of the box (row by row) is covered.  One sample per
+// pixel, at most 32 pixels (micro_pixels<1>()).
+__device__ inline uint32_t micro_coverage_mask(const MicroEdges& e, int x0, int y0, int npx, int npy)
+{
+    const int32_t sxa = -(e.cy - e.by) * kSubpix, sya = (e.cx - e.bx) * kSubpix;
+    const int32_t sxb = -(e.ay - e.cy) * kSubpix, syb = (e.ax - e.cx) * kSubpix;
+    const int32_t sxc = -(e.by - e.ay) * kSubpix, syc = (e.bx - e.ax) * kSubpix;
+    const int32_t wxa = sya - (npx - 1) * sxa, wxb = syb - (npx - 1) * sxb, wxc = syc - (npx - 1) * sxc;
+    int32_t Ea, Eb, Ec;
+    micro_eval(e, x0 * kSubpix + kHalf, y0 * kSubpix + kHalf, Ea, Eb, Ec);
+    Ea += e.bias_a; Eb += e.bias_b; Ec += e.bias_c;
+    uint32_t mask = 0, bit = 1u;
+    int i = 0;
+    for (int n = npx * npy; n > 0; --n) {
+        mask |= (Ea | Eb | Ec) >= 0 ? bit : 0u;
+        bit <<= 1;
+        const bool wrap = ++i == npx;
+        Ea += wrap ? wxa : sxa; Eb += wrap ? wxb : sxb; Ec += wrap ? wxc : sxc;
+        i = wrap ? 0 : i;
+    }
+    return mask;
+}
+
+// SR_WAVE_SYNC(): the lanes of a wave have written LDS words other lanes of the same wave read next.  On the GPU a wave's LDS
+// instructions execute in program order for all its lanes, so this is a fence for the compiler only; where the kernels are executed
+// lane by lane on the CPU (the tests) it is the point at which the wave's lanes wait for each other.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define SR_WAVE_SYNC() ((void)__ballot(1))
+#endif
+
 // The pixels whose sample points the bounding box of a triangle can hold, clipped to the stored rectangle: false if there are none.
 template <int S>
 __device__ inline bool sample_box(int mnx, int mxx, int mny, int mxy, const FrameGeom& g, int& x0, int& y0, int& npx, int& npy)
@@ -371,7 +403,7 @@ __device__ inline T plane_at(const T* plane, uint32_t byte_offset)
 // one or two vertices that cannot be projected go on the clip list; whatever is left is handed to the
 // binning kernel through the view's pending list (ballots and prefix counts inside the block, one
 // atomic add per block that has any).
-template <int S, bool VIEW_LOOP>
+template <int S, bool VIEW_LOOP, bool STAGED>
 __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                     FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, BlockFlags flags,
                                                     uint32_t view0, uint32_t n_views, uint32_t views_per_block, const uint32_t* __restrict__ chunk_visible)
@@ -383,6 +415,21 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     constexpr uint32_t kQueues = VIEW_LOOP ? 2u : 1u;
     __shared__ uint32_t s_q_tri[kQueues][kSetupBlockTris], s_q_i0[kQueues][kSetupBlockTris], s_q_i1[kQueues][kSetupBlockTris], s_q_i2[kQueues][kSetupBlockTris];
     __shared__ uint32_t s_q_count[3];
+    // Staged resolve (STAGED: one sample, one view per workgroup, a launch of thousands of workgroups).  An atomic minimum costs what
+    // the 128-byte lines its instruction touches cost (measured: 64 lanes in 4 lines 155 G operations/s, in 64 lines 25 G/s), and a
+    // lane that walks its own box fires in a few of its turns only: instructions with a fifth of the lanes active, each in a line of
+    // its own.  So the lanes first only mark their covered samples (a 32-bit mask), the wave counts them and numbers them triangle by
+    // triangle, every covered sample is written to the wave's stretch of LDS in that order, and the wave then resolves the stretch
+    // with all its lanes: full instructions whose neighbouring lanes are neighbouring samples.  Set-up of the 10 M-triangle frame:
+    // 74.6 -> 59.7 us at 3840 x 2160 (1.9 M samples), 268 -> 117 us at 7680 x 4320 (7.8 M).  A launch of a few hundred workgroups is
+    // bound by the latency of a workgroup's chain of steps instead, which the two passes lengthen (124 000 triangles at 1080p:
+    // 22 -> 33 us): such launches keep the resolve inside the walk.
+    static_assert(!STAGED || (S == 1 && !VIEW_LOOP), "the staged resolve is built for one sample and one view per workgroup");
+    constexpr bool kStaged = STAGED;
+    constexpr uint32_t kStageCap = kStaged ? 160u : 1u;            // covered samples a wave resolves per round
+    __shared__ uint32_t s_f_off[4][kStageCap], s_f_z[4][kStageCap], s_f_tri[4][kStageCap];
+    __shared__ uint32_t s_inv[33];                                  // s_inv[n] = 65535 / n + 1: bit / n == (bit * s_inv[n]) >> 16 for bit < 64, n <= 32
+    if (kStaged && threadIdx.x >= 1u && threadIdx.x <= 32u) s_inv[threadIdx.x] = 65535u / threadIdx.x + 1u;
     const uint32_t turn = xcd_runs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const uint32_t blk = turn % gridDim.x, view_begin = turn / gridDim.x * views_per_block;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
@@ -505,6 +552,68 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             const uint32_t q = q0 + tid;
             bool drawn = false;
             uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;   // blocks of flags the drawn triangle's box reaches into
+            if constexpr (kStaged) {
+                uint32_t mask = 0, t = 0, inv = 0;
+                int x0 = 0, y0 = 0, npx = 1, npy = 1;
+                MicroEdges e{};
+                float za = 0.0f, zb = 0.0f, zc = 0.0f, rA = 0.0f;
+                if (q < n_q) {
+                    t = s_q_tri[qb][q];
+                    const uint32_t j0 = s_q_i0[qb][q], j1 = s_q_i1[qb][q], j2 = s_q_i2[qb][q];
+                    const int2 a0 = plane_at(xy, j0), a1 = plane_at(xy, j1), a2 = plane_at(xy, j2);
+                    za = plane_at(zp, j0 >> 1); zb = plane_at(zp, j1 >> 1); zc = plane_at(zp, j2 >> 1);
+                    sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
+                    const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
+                    rA = 1.0f / (float)A;
+                    e = micro_edges(a0, a1, a2);
+                    mask = micro_coverage_mask(e, x0, y0, npx, npy);
+                    inv = s_inv[npx];                          // (1 <= npx <= 32: the box holds a sample point and at most micro_pixels<1>() pixels)
+                    drawn = mask != 0u;
+                    bx0 = (uint32_t)(x0 - g.rx) / kFlagBlockW; bx1 = (uint32_t)(x0 + npx - 1 - g.rx) / kFlagBlockW;
+                    by0 = (uint32_t)(y0 - g.ry) / kFlagBlockH; by1 = (uint32_t)(y0 + npy - 1 - g.ry) / kFlagBlockH;
+                }
+                // number the wave's covered samples triangle by triangle (every lane of the wave is here: the loop over the queue takes
+                // the same number of turns for all)
+                const uint32_t cnt = (uint32_t)__popc(mask);
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+                const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+                uint32_t next = incl - cnt;                    // number of this lane's next covered sample
+                // first sample of the box: unbiased edge values, and their steps per pixel in x and y
+                int32_t Ea0, Eb0, Ec0;
+                micro_eval(e, x0 * kSubpix + kHalf, y0 * kSubpix + kHalf, Ea0, Eb0, Ec0);
+                const int32_t sxa = -(e.cy - e.by) * kSubpix, sya = (e.cx - e.bx) * kSubpix;
+                const int32_t sxb = -(e.ay - e.cy) * kSubpix, syb = (e.ax - e.cx) * kSubpix;
+                const int32_t sxc = -(e.by - e.ay) * kSubpix, syc = (e.bx - e.ax) * kSubpix;
+                const uint32_t first_off = (uint32_t)(y0 - g.ry) * (uint32_t)g.rw + (uint32_t)(x0 - g.rx);
+                for (uint32_t w0 = 0; w0 < total; w0 += kStageCap) {          // rounds: the same number for every lane of the wave
+                    const uint32_t w1 = min(w0 + kStageCap, total);
+                    while (mask != 0u && next < w1) {
+                        const uint32_t bit = (uint32_t)__ffs((int)mask) - 1u;
+                        mask &= mask - 1u;
+                        const uint32_t dy = (bit * inv) >> 16, dx = bit - dy * (uint32_t)npx;
+                        // (every factor is small: |step| < 2^22, dx, dy < 32; the sums are the walk's values, exact in 32 bits)
+                        const int32_t Ea = Ea0 + __mul24((int)dx, sxa) + __mul24((int)dy, sya);
+                        const int32_t Eb = Eb0 + __mul24((int)dx, sxb) + __mul24((int)dy, syb);
+                        const int32_t Ec = Ec0 + __mul24((int)dx, sxc) + __mul24((int)dy, syc);
+                        const float l0 = (float)Ea * rA, l2 = (float)Eb * rA, l1 = (float)Ec * rA;
+                        float z = fmaf(l2, zc, fmaf(l1, zb, l0 * za));
+                        z = z + 0.0f;
+                        const uint32_t slot = next - w0;
+                        s_f_off[wave][slot] = z >= 0.0f && z < 1.0f ? first_off + dy * (uint32_t)g.rw + dx : 0xFFFFFFFFu;   // outside the clip volume in z: not drawn
+                        s_f_z[wave][slot] = __float_as_uint(z);
+                        s_f_tri[wave][slot] = t;
+                        ++next;
+                    }
+                    SR_WAVE_SYNC();
+                    for (uint32_t j = lane; j < w1 - w0; j += 64u) {
+                        const uint32_t off = s_f_off[wave][j];
+                        if (off != 0xFFFFFFFFu) atomicMin(vis_view + off, ((unsigned long long)s_f_z[wave][j] << 32) | (unsigned long long)s_f_tri[wave][j]);
+                    }
+                    SR_WAVE_SYNC();                             // (the stretch is read before the next round overwrites it)
+                }
+            } else
             if (q < n_q) {
                 const uint32_t t = s_q_tri[qb][q], j0 = s_q_i0[qb][q], j1 = s_q_i1[qb][q], j2 = s_q_i2[qb][q];
                 const int2 a0 = plane_at(xy, j0), a1 = plane_at(xy, j1), a2 = plane_at(xy, j2);
@@ -1929,7 +2038,7 @@ static inline uint32_t chunk_grid(const BinBuffers& b) { return std::min<uint32_
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags, uint32_t view0, hipEvent_t between,
-                  bool bin, uint32_t fill_blocks, const uint32_t* chunk_visible)
+                  bool bin, uint32_t fill_blocks, const uint32_t* chunk_visible, uint32_t staged_min_blocks)
 {
     if (!n_tris || !n_views) return;
     // a workgroup takes every view of the pass for its triangles, unless the mesh is too small to fill the chip that way
@@ -1937,11 +2046,14 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
     const uint32_t views_per_block = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views);
     const dim3 grid(grid_x, div_up(n_views, views_per_block));
     if (views_per_block == 1) {
-        if (g.samples == 1) setup_kernel<1, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
-        else setup_kernel<4, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
+        // (the staged resolve where the launch is long enough to be bound by what it does, not by how long one workgroup takes)
+        const bool staged = g.samples == 1 && (uint64_t)grid.x * grid.y >= staged_min_blocks;
+        if (staged) setup_kernel<1, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
+        else if (g.samples == 1) setup_kernel<1, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
+        else setup_kernel<4, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
     } else {
-        if (g.samples == 1) setup_kernel<1, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr);
-        else setup_kernel<4, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr);
+        if (g.samples == 1) setup_kernel<1, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr);
+        else setup_kernel<4, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr);
     }
     if (between) (void)hipEventRecord(between, st);
     if (!bin) return;

@@ -30,6 +30,9 @@ void launch_split_positions(hipStream_t st, const void* aos, uint32_t n, float* 
 // fill_blocks (here and in launch_setup): a workgroup handles its vertices / triangles for EVERY view of the launch, loading positions /
 // indices once -- unless that leaves fewer than about fill_blocks workgroups, in which case the views are spread over more of them
 constexpr uint32_t kFillBlocks = 4096;
+// set-up workgroups (one view each, one sample) from which a launch resolves its micro-triangles' samples through LDS, whole waves at a
+// time, instead of inside each lane's walk: two per workgroup slot of the chip -- a launch long enough to be bound by what it does
+constexpr uint32_t kStagedResolveMinBlocks = 4096;
 void launch_vertex(hipStream_t st, const float* px, const float* py, const float* pz, uint32_t n, const ViewXform* views, uint32_t n_views,
                    int W, int H, const ScreenPlanes& out, ScreenVertex* debug_out, float* clip_out, uint32_t fill_blocks = kFillBlocks);
 // vis: the target's whole visibility buffer, of which the flagged blocks of views [view0, view0 + n_views) are cleared;
@@ -46,7 +49,8 @@ bool launch_vertex_and_begin(hipStream_t st, const float* px, const float* py, c
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags /* of the target */, uint32_t view0,
                   hipEvent_t between /* recorded between set-up and binning, may be null */, bool bin = true /* false: set-up only */,
-                  uint32_t fill_blocks = kFillBlocks, const uint32_t* chunk_visible = nullptr /* chunk culling: one-view draws only */);
+                  uint32_t fill_blocks = kFillBlocks, const uint32_t* chunk_visible = nullptr /* chunk culling: one-view draws only */,
+                  uint32_t staged_min_blocks = kStagedResolveMinBlocks);
 // chunk culling (sr_device.h): bounds of every chunk of setup_block_triangles() triangles, once per mesh; the per-draw test
 void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint2* vrange);
 void launch_chunk_cull(hipStream_t st, const ChunkCull& cc, const CullView& v, const FrameGeom& g);
