@@ -5,6 +5,7 @@
 #include "sr_launch.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace sr {
@@ -1311,15 +1312,22 @@ struct TrilinearTaps {
     Taps hi, lo;
     float delta;
 };
-// texture() with the 2x2-quad differences supplied; isotropic LOD, trilinear, REPEAT
-__device__ inline TrilinearTaps trilinear_taps(const TexDesc& t, const uint32_t* lvl, float s, float tt, float dsdx, float dtdx, float dsdy, float dtdy)
+// log2 of the isotropic scale factor rho of a texture under the 2x2-quad differences of its coordinates: the level of detail before
+// the sampler's bias and clamps
+__device__ inline float lod_of_footprint(const TexDesc& t, float dsdx, float dtdx, float dsdy, float dtdy)
 {
     SR_COLOUR_MATH
     const float mux = dsdx * (float)t.w, mvx = dtdx * (float)t.h;
     const float muy = dsdy * (float)t.w, mvy = dtdy * (float)t.h;
     const float rx2 = mux * mux + mvx * mvx, ry2 = muy * muy + mvy * mvy;
     const float r2 = rx2 > ry2 ? rx2 : ry2;
-    float lambda = 0.5f * __builtin_amdgcn_logf(r2) + t.bias;
+    return 0.5f * __builtin_amdgcn_logf(r2);
+}
+// texture() with log2(rho) supplied; trilinear, REPEAT
+__device__ inline TrilinearTaps trilinear_taps_at(const TexDesc& t, const uint32_t* lvl, float s, float tt, float log2_rho)
+{
+    SR_COLOUR_MATH
+    float lambda = log2_rho + t.bias;
     if (!(lambda > t.min_lod)) lambda = t.min_lod;
     if (lambda > t.max_lod) lambda = t.max_lod;
     const float q = (float)(t.levels - 1);
@@ -1332,6 +1340,11 @@ __device__ inline TrilinearTaps trilinear_taps(const TexDesc& t, const uint32_t*
     tp.lo = tp.hi;
     if (tp.delta != 0.0f) tp.lo = level_taps(t, lvl, llo, s, tt);
     return tp;
+}
+// texture() with the 2x2-quad differences supplied; isotropic LOD, trilinear, REPEAT
+__device__ inline TrilinearTaps trilinear_taps(const TexDesc& t, const uint32_t* lvl, float s, float tt, float dsdx, float dtdx, float dsdy, float dtdy)
+{
+    return trilinear_taps_at(t, lvl, s, tt, lod_of_footprint(t, dsdx, dtdx, dsdy, dtdy));
 }
 template <int NCH>
 __device__ inline void fetch_trilinear(const uint32_t* texels, const TrilinearTaps& tp, const float* dec, float* o)
@@ -1446,7 +1459,7 @@ __device__ inline void fragment_main(const float* wp, const float* N, const floa
     for (int c = 0; c < 3; ++c) { F0[c] = fmaf(albedo[c], metallic, 0.04f * one_m); diff[c] = albedo[c] * kInvPI * one_m; }
     float Lo[3] = { 0.0f, 0.0f, 0.0f };
     const float power[3] = { 23.47f, 21.31f, 20.79f };
-    const float NdotV = max0(dot3(N, V));
+    const float NdV = dot3(N, V), NdotV = max0(NdV);
     const float a = roughness * roughness, a2 = a * a;
     const float gv = geometry_schlick_ggx(NdotV, roughness);
     const float rp1 = roughness + 1.0f, gk = (rp1 * rp1) * 0.125f;   // k of GeometrySchlickGGX
@@ -1455,19 +1468,20 @@ __device__ inline void fragment_main(const float* wp, const float* N, const floa
     for (int i = 0; i < 4; ++i) {
         const float lp[3] = { (i & 1) ? 10.0f : -10.0f, (i & 2) ? -10.0f : 10.0f, 10.0f };
         const float D[3] = { lp[0] - wp[0], lp[1] - wp[1], lp[2] - wp[2] };
-        float L[3], Hv[3];
         const float dd = dot3(D, D);
         const float invd = frsq(dd);
-        L[0] = D[0] * invd; L[1] = D[1] * invd; L[2] = D[2] * invd;
-        t[0] = V[0] + L[0]; t[1] = V[1] + L[1]; t[2] = V[2] + L[2];
-        normalize3(t, Hv);
+        // L = D * invd and H = normalize(V + L) are never formed: with |V| = |L| = 1, |V + L|^2 = 2 + 2 V.L, so every dot product
+        // with H follows from the dot products with V and D (N is NOT a unit vector here -- the shader never normalises it -- and
+        // need not be)
+        const float NdL = dot3(N, D) * invd, VdL = dot3(V, D) * invd;
+        const float inv_t = frsq(fmaf(2.0f, VdL, 2.0f));
         const float attenuation = invd * invd;           // 1 / dot(D, D)
-        const float NdotH = max0(dot3(N, Hv)), NdotH2 = NdotH * NdotH;
+        const float NdotH = max0((NdV + NdL) * inv_t), NdotH2 = NdotH * NdotH;
         float denom = fmaf(NdotH2, a2 - 1.0f, 1.0f);
         denom = kPI * denom * denom;                      // NDF = a2 / denom
-        const float NdotL = max0(dot3(N, L));
+        const float NdotL = max0(NdL);
         const float gl = fmaf(NdotL, 1.0f - gk, gk);      // G = NdotL / gl * gv
-        const float x1 = 1.0f - max0(dot3(Hv, V));
+        const float x1 = 1.0f - max0((1.0f + VdL) * inv_t);   // 1 - max(dot(H, V), 0)
         const float x2 = x1 * x1;
         const float fc = x2 * x2 * x1;                    // pow(x, 5.0)
         const float denominator = fmaf(4.0f * NdotV, NdotL, 0.001f);
@@ -1503,6 +1517,8 @@ struct FragParams {
     ShadeTables tab;
     uint32_t view0;            // first view of this pass inside the target
     uint32_t paired;           // 1: the metallic and roughness maps have the same size and sampler state, so one set of footprints serves both
+    uint32_t lod_shared;       // bit 0 / 1: the metallic / roughness map has the albedo map's proportions (w_m * h_a == h_m * w_a), so its
+    float lod_shift[2];        // log2(rho) is the albedo map's + lod_shift = log2(w_m / w_a)
     BlockFlags flags;          // written here, read by the start of the next draw
     PassReport report;         // host_counters != null: the first workgroup reports the counters of the pass to the host (a lean
                                // draw, which has no scan kernel to do it)
@@ -1639,11 +1655,18 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
         sample_texture_aniso<1>(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, met);
         sample_texture_aniso<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
     } else {
-        sample_texture<3>(p.albedo, lvl, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
-        const TrilinearTaps tm = trilinear_taps(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy);
+        // A map with the albedo map's proportions scales its footprint by a constant: its log2(rho) is the albedo map's plus the
+        // logarithm of the ratio of the widths (FragParams::lod_shift) -- one logarithm per pixel instead of three.
+        const float la = lod_of_footprint(p.albedo, dudx, dvdx, dudy, dvdy);
+        fetch_trilinear<3>(p.albedo.texels, trilinear_taps_at(p.albedo, lvl, u, v, la), dec, alb);
+        const float lm = p.lod_shared & 1u ? la + p.lod_shift[0] : lod_of_footprint(p.metallic, dudx, dvdx, dudy, dvdy);   // (the same choice for the whole launch)
+        const TrilinearTaps tm = trilinear_taps_at(p.metallic, lvl + kMaxMipLevels, u, v, lm);
         fetch_trilinear<1>(p.metallic.texels, tm, dec, met);
         if (p.paired) fetch_trilinear<1>(p.roughness.texels, tm, dec, rgh);    // the same for the whole launch
-        else sample_texture<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+        else {
+            const float lr = p.lod_shared & 2u ? la + p.lod_shift[1] : lod_of_footprint(p.roughness, dudx, dvdx, dudy, dvdy);
+            fetch_trilinear<1>(p.roughness.texels, trilinear_taps_at(p.roughness, lvl + 2 * kMaxMipLevels, u, v, lr), dec, rgh);
+        }
     }
     float lg[3];
     fragment_main(wp, N, vx.cam, alb, met[0], rgh[0], rgb, lg);
@@ -2133,6 +2156,13 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
     const TexDesc &m = f.metallic, &r = f.roughness;
     p.paired = m.w == r.w && m.h == r.h && m.levels == r.levels && m.min_lod == r.min_lod && m.max_lod == r.max_lod && m.bias == r.bias &&
                std::memcmp(m.level_off, r.level_off, sizeof m.level_off) == 0;
+    p.lod_shared = 0u; p.lod_shift[0] = p.lod_shift[1] = 0.0f;
+    const TexDesc* other[2] = {&f.metallic, &f.roughness};
+    for (int k = 0; k < 2; ++k)
+        if ((int64_t)other[k]->w * f.albedo.h == (int64_t)other[k]->h * f.albedo.w) {
+            p.lod_shared |= 1u << k;
+            p.lod_shift[k] = (float)std::log2((double)other[k]->w / (double)f.albedo.w);
+        }
     const dim3 grid(div_up((uint32_t)f.g.rw, kFragBlockW), div_up((uint32_t)f.g.rh, kFragBlockH), f.n_views), block(kFragBlockW, kFragBlockH);
     // the anisotropic footprint is compiled in only when a bound sampler asks for it
     const bool aniso = f.albedo.max_aniso > 1.0f || f.metallic.max_aniso > 1.0f || f.roughness.max_aniso > 1.0f ||
