@@ -329,6 +329,27 @@ __device__ inline ScreenVertex project_clip_coords(const float* clip, int W, int
     return sv;
 }
 
+// The same record without branches, for callers inside long straight-line code (the shading pass): everything is computed
+// whatever w is and the conditions select at the end.  Every operation on the path of a projectable vertex is the one
+// project_clip_coords performs, in the same order, so the record is the same bit for bit; a vertex that fails a test gets
+// the same zeros.
+__device__ inline ScreenVertex project_clip_coords_select(const float* clip, int W, int H)
+{
+    const float w = clip[3];
+    const float rw = 1.0f / w;
+    const float xd = clip[0] * rw, yd = clip[1] * rw;
+    const float hw = (float)W * 0.5f, hh = (float)H * 0.5f;
+    const float xf = xd * hw + hw;
+    const float yf = yd * (-hh) + hh;
+    const bool ok = (w > 0.0f) & (fabsf(xf) <= kGuardPx) & (fabsf(yf) <= kGuardPx) & (rw > 0.0f) & (rw <= 3.4028234e38f);   // (false for NaNs; the last: rw is not infinite)
+    ScreenVertex sv;
+    sv.X = ok ? (int32_t)rintf(xf * (float)kSubpix) : 0;
+    sv.Y = ok ? (int32_t)rintf(yf * (float)kSubpix) : 0;
+    sv.z = 0.0f;                 // (not needed by the callers of this form)
+    sv.rw = ok ? rw : 0.0f;
+    return sv;
+}
+
 // The clipper proper.  The triangle is clipped in clip space against the near plane (z >= 0) and then against four
 // side planes |x| <= K_x w, |y| <= K_y w that keep every cut point 2^19 pixels or less from the frame (inside the
 // guard band).  Two rules make the result fit the triangles around it:

@@ -1222,17 +1222,16 @@ struct ShadeTables {
     const float* thresh;   // 255: linear value where the code steps from c to c+1
 };
 
-// log2_x: log2(x), or anything near it -- it only seeds the search, the thresholds decide
+// The code of x is the number of thresholds not above it (thresh[c] = the linear value at which the code steps from c to c + 1,
+// ascending).  The transfer function, evaluated with the hardware's exp2 (log2_x: log2(x), accurate to a few ulp), gives the code
+// to within one; the three thresholds around that estimate then decide exactly -- no loop, no branch.  A NaN or a negative x gives 0.
 __device__ inline int srgb_encode8(float x, const float* thresh /* LDS or global, 255 entries */, float log2_x)
 {
-    if (!(x > 0.0f)) return 0;
-    if (x >= thresh[254]) return 255;
+    x = fmaxf(x, 0.0f);                                     // (a NaN becomes 0)
     const float e = x <= 0.0031308f ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(log2_x * (1.0f / 2.4f)) - 0.055f;
-    int c = (int)(e * 255.0f + 0.5f);
-    c = min(max(c, 0), 254);
-    while (c < 254 && x >= thresh[c]) ++c;      // exact: smallest c with x < thresh[c]
-    while (c > 0 && x < thresh[c - 1]) --c;
-    return c;
+    int c = (int)(e * 255.0f + 0.5f);                       // within one of the code (the estimate is good to 1e-5 of a step)
+    c = min(max(c, 1), 253);                                // so that c - 1 .. c + 1 are thresholds: the result spans 0 .. 255
+    return c - 1 + (x >= thresh[c - 1]) + (x >= thresh[c]) + (x >= thresh[c + 1]);
 }
 __device__ inline int srgb_encode8(float x, const float* thresh) { return srgb_encode8(x, thresh, __builtin_amdgcn_logf(x)); }
 __device__ inline int unorm_encode8(float x)
@@ -1550,18 +1549,21 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     float w0[4], w1[4], w2[4], n0[3], n1[3], n2[3];   // world-space positions and normals of the three vertices
     ScreenVertex v0, v1, v2;
     if constexpr (IDENT) {
-        w0[0] = a0.x + 0.0f; w0[1] = a0.y + 0.0f; w0[2] = a0.z + 0.0f;
-        w1[0] = a1.x + 0.0f; w1[1] = a1.y + 0.0f; w1[2] = a1.z + 0.0f;
-        w2[0] = a2.x + 0.0f; w2[1] = a2.y + 0.0f; w2[2] = a2.z + 0.0f;
+        // (the general product with the identity returns p + 0, which differs from p for a negative zero only; the sign of a zero
+        // coordinate changes neither a window position -- every clip coordinate is a sum that contains the non-zero w term or is
+        // a zero of either sign, which the viewport transform takes to the same value -- nor an interpolated value)
+        w0[0] = a0.x; w0[1] = a0.y; w0[2] = a0.z;
+        w1[0] = a1.x; w1[1] = a1.y; w1[2] = a1.z;
+        w2[0] = a2.x; w2[1] = a2.y; w2[2] = a2.z;
         n0[0] = a0.w; n0[1] = b0.x; n0[2] = b0.y;
         n1[0] = a1.w; n1[1] = b1.x; n1[2] = b1.y;
         n2[0] = a2.w; n2[1] = b2.x; n2[2] = b2.y;
         mat4_mul_vec4(vx.pv, w0[0], w0[1], w0[2], 1.0f, c0);
         mat4_mul_vec4(vx.pv, w1[0], w1[1], w1[2], 1.0f, c1);
         mat4_mul_vec4(vx.pv, w2[0], w2[1], w2[2], 1.0f, c2);
-        v0 = project_clip_coords(c0, p.g.W, p.g.H);
-        v1 = project_clip_coords(c1, p.g.W, p.g.H);
-        v2 = project_clip_coords(c2, p.g.W, p.g.H);
+        v0 = project_clip_coords_select(c0, p.g.W, p.g.H);
+        v1 = project_clip_coords_select(c1, p.g.W, p.g.H);
+        v2 = project_clip_coords_select(c2, p.g.W, p.g.H);
     } else {
         v0 = project_vertex(vx, a0.x, a0.y, a0.z, p.g.W, p.g.H, c0);
         v1 = project_vertex(vx, a1.x, a1.y, a1.z, p.g.W, p.g.H, c1);
