@@ -1258,26 +1258,30 @@ __device__ inline Taps level_taps(const TexDesc& tex, const uint32_t* lvl /* lev
 {
     SR_COLOUR_MATH
     const uint32_t base = lvl[level];   // (an LDS copy: a per-lane index into kernel arguments would be a memory load)
-    const bool pow2 = tex.log2_w >= 0;   // the same for the whole launch
-    const int sw = max(tex.log2_w - level, 0);
-    const int wl = pow2 ? 1 << sw : max(tex.w >> level, 1), hl = pow2 ? 1 << max(tex.log2_h - level, 0) : max(tex.h >> level, 1);
-    const float u = s * (float)wl - 0.5f, v = tt * (float)hl - 0.5f;
     const float lim = 1073741824.0f;
-    const float fu = fminf(fmaxf(floorf(u), -lim), lim), fv = fminf(fmaxf(floorf(v), -lim), lim);   // (a NaN becomes -lim)
-    const float a = u - floorf(u), b = v - floorf(v);
-    int i0, j0, i1, j1;
-    uint32_t r0, r1;   // a chain holds fewer than 2^30 texels (16384^2 * 4/3)
-    if (pow2) {   // wrap with a mask, rows by a shift
-        i0 = (int)fu & (wl - 1); j0 = (int)fv & (hl - 1);
-        i1 = (i0 + 1) & (wl - 1); j1 = (j0 + 1) & (hl - 1);
-        r0 = base + ((uint32_t)j0 << sw); r1 = base + ((uint32_t)j1 << sw);
-    } else {
-        i0 = wrap_repeat((int)fu, wl); j0 = wrap_repeat((int)fv, hl);
-        i1 = wrap_repeat(i0 + 1, wl); j1 = wrap_repeat(j0 + 1, hl);
-        r0 = base + (uint32_t)j0 * (uint32_t)wl; r1 = base + (uint32_t)j1 * (uint32_t)wl;
-    }
     Taps t;
-    t.o00 = r0 + (uint32_t)i0; t.o10 = r0 + (uint32_t)i1; t.o01 = r1 + (uint32_t)i0; t.o11 = r1 + (uint32_t)i1;
+    float a, b;
+    uint32_t r0, r1, i0, i1;   // a chain holds fewer than 2^30 texels (16384^2 * 4/3)
+    if (tex.log2_w >= 0) {     // both sizes powers of two (the same for the whole launch): scale by an exponent, wrap with a mask, rows by a shift
+        const int sw = max(tex.log2_w - level, 0), sh = max(tex.log2_h - level, 0);
+        const float u = ldexpf(s, sw) - 0.5f, v = ldexpf(tt, sh) - 0.5f;              // s * 2^sw, exactly what the product with the level's width gives
+        const float flu = floorf(u), flv = floorf(v);
+        a = u - flu; b = v - flv;
+        const uint32_t mw = (1u << sw) - 1u, mh = (1u << sh) - 1u;
+        i0 = (uint32_t)(int)fminf(fmaxf(flu, -lim), lim) & mw;                          // (a NaN becomes -lim)
+        const uint32_t j0 = (uint32_t)(int)fminf(fmaxf(flv, -lim), lim) & mh;
+        i1 = (i0 + 1u) & mw;
+        r0 = base + (j0 << sw); r1 = base + (((j0 + 1u) & mh) << sw);
+    } else {
+        const int wl = max(tex.w >> level, 1), hl = max(tex.h >> level, 1);
+        const float u = s * (float)wl - 0.5f, v = tt * (float)hl - 0.5f;
+        const float flu = floorf(u), flv = floorf(v);
+        a = u - flu; b = v - flv;
+        const int x0 = wrap_repeat((int)fminf(fmaxf(flu, -lim), lim), wl), y0 = wrap_repeat((int)fminf(fmaxf(flv, -lim), lim), hl);
+        i0 = (uint32_t)x0; i1 = (uint32_t)wrap_repeat(x0 + 1, wl);
+        r0 = base + (uint32_t)y0 * (uint32_t)wl; r1 = base + (uint32_t)wrap_repeat(y0 + 1, hl) * (uint32_t)wl;
+    }
+    t.o00 = r0 + i0; t.o10 = r0 + i1; t.o01 = r1 + i0; t.o11 = r1 + i1;
     t.w00 = (1.0f - a) * (1.0f - b); t.w10 = a * (1.0f - b); t.w01 = (1.0f - a) * b; t.w11 = a * b;
     return t;
 }
