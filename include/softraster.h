@@ -86,7 +86,8 @@ typedef struct sr_draw_stats {
  * counters then show that it needed them, it is issued again in full before anything of it can be observed. */
 typedef struct sr_draw_counts {
     uint64_t draws;               /* sr_draw / sr_draw_no_alloc calls that issued kernels */
-    uint64_t lean_draws;          /* of them, issued lean */
+    uint64_t lean_draws;          /* of them, issued lean (including those that also ran the direct rasteriser for a few pending triangles) */
+    uint64_t direct_draws;        /* lean draws that resolved their pending triangles straight into the visibility buffer instead of through tile lists */
     uint64_t lean_redraws;        /* lean draws that had to be issued again in full */
     uint64_t overflow_redraws;    /* draws issued again because the tile reference list was too small */
     uint64_t chunks_tested;       /* one-view draws into a target restricted to a rectangle test every chunk of 768 consecutive triangles */

@@ -358,6 +358,79 @@ def test_lean_draws_and_their_fallback(sr, oracle, anisotropic):
         dev.close()
 
 
+@pytest.mark.parametrize("samples", [1, 4])
+def test_few_pending_triangles_take_the_direct_rasteriser(sr, oracle, samples, anisotropic):
+    """When a target's previous draw left only a few thousand small triangles for the tile lists, the next draw of the same mesh
+    resolves them with one kernel straight into the visibility buffer (no binning, scan, fill, tile rasteriser).  The reference's
+    own frame drawn three times (tile path, then twice direct), two views at once, a stored rectangle, a camera close to the surface
+    (vertices behind the eye: the clipper rides along), and a scene with one triangle far too large for that kernel (the draw is
+    repeated through the tile path): every frame, and its counters, equal the oracle's."""
+    import math
+    W, H = 400, 300
+    images = sr.scene.material_textures(64, seed=6)
+    sphere = sr.scene.uv_sphere(88, 88)
+    dev = sr.Device(0)
+    try:
+        tex = [sr.create_texture(dev, im) for im in images]
+        mesh = sr.create_mesh_from_data(dev, *sphere)
+        # one target, three draws; then a second target of two views and a third with a rectangle
+        for n_views, rect in ((1, None), (2, None), (1, (37, 50, 301, 177))):
+            tgt = sr.RenderTarget(dev, W, H, samples=samples, n_views=n_views, rect=rect)
+            ubos = sr.scene.orbit_ubos(3, W, H)
+            for k in range(3):
+                before = dev.draw_counts()
+                u = ubos[k:k + 1] if n_views == 1 else np.stack([ubos[k], ubos[(k + 1) % 3]])
+                sr.draw(dev, tgt, mesh, u, tex)
+                for v in range(n_views):
+                    got = {"tri": tgt.read_triangle_ids(v), "depth": tgt.read_depth(v), "bgra": tgt.read_color(v)}
+                    _check_view(got, oracle.draw(u[v], sphere[0], sphere[1], images, W, H, samples, rect=rect, threads=4))
+                st, after = tgt.stats(), dev.draw_counts()
+                assert st["triangles_binned"] > 100 * n_views
+                assert after["direct_draws"] - before["direct_draws"] == (1 if k > 0 else 0), (n_views, rect, k)
+                assert after["lean_redraws"] == before["lean_redraws"]
+            tgt.destroy()
+        # the eye just above the surface: part of the sphere is behind the eye plane, the clipper is needed; the second and third draw are direct
+        e = np.array([0.0, -1.02, 0.0])
+        close = sr.scene.make_ubo(np.eye(4, dtype=np.float32), sr.scene.look_at(e, (0.9, -0.9, 0.1), (0.0, 0.0, 1.0)),
+                                  sr.scene.perspective(math.radians(45.0), W / H, 0.002, 10.0), e)
+        tgt = sr.RenderTarget(dev, W, H, samples=samples)
+        for k in range(3):
+            sr.draw(dev, tgt, mesh, close, tex)
+            got = {"tri": tgt.read_triangle_ids(0), "depth": tgt.read_depth(0), "bgra": tgt.read_color(0)}
+            ref = oracle.draw(close, sphere[0], sphere[1], images, W, H, samples, threads=4)
+            _check_view(got, ref)
+            st = tgt.stats()
+            assert st["triangles_clipped"] == ref["stats"]["tris_clipped"] > 0 and st["triangles_unprojectable"] == 0
+        tgt.destroy(); mesh.destroy()
+        # small triangles and one that covers most of the frame: the direct draw is given up and repeated, and not tried again
+        verts, idx = util.random_soup(900, 8, size=0.12)
+        big = np.zeros((3, 8), np.float32)
+        big[:, :3] = [[-2.5, 0.4, -1.4], [0.6, -2.4, -1.2], [0.3, 0.5, 1.9]]
+        big[:, 5] = 1.0
+        ubo = sr.scene.default_camera_ubo(W, H)
+        if oracle.draw(ubo, big, np.arange(3, dtype=np.uint32), images, W, H, samples, shade=False)["stats"]["shaded_px"] == 0:
+            big = big[::-1].copy()
+        verts = np.concatenate([verts, big]); idx = np.concatenate([idx, np.arange(3, dtype=np.uint32) + 2700]).astype(np.uint32)
+        mesh = sr.create_mesh_from_data(dev, verts, idx)
+        tgt = sr.RenderTarget(dev, W, H, samples=samples)
+        ref = oracle.draw(ubo, verts, idx, images, W, H, samples, threads=4)
+        assert (ref["tri"] == 900).sum() > W * H * samples // 8      # the large triangle shows
+        redraws = []
+        for k in range(4):
+            before = dev.draw_counts()
+            sr.draw(dev, tgt, mesh, ubo, tex)
+            _check_view({"tri": tgt.read_triangle_ids(0), "depth": tgt.read_depth(0), "bgra": tgt.read_color(0)}, ref)
+            after = dev.draw_counts()
+            redraws.append((after["direct_draws"] - before["direct_draws"], after["lean_redraws"] - before["lean_redraws"]))
+        assert redraws[0] == (0, 0) and redraws[2] == (0, 0) and redraws[3] == (0, 0), redraws     # (the second may or may not try, by the first's references per triangle)
+        assert redraws[1] in ((0, 0), (1, 1)), redraws
+        tgt.destroy(); mesh.destroy()
+        for t in tex:
+            t.destroy()
+    finally:
+        dev.close()
+
+
 def test_model_and_textures_from_files(sr, oracle, device, tmp_path):
     """Model::load and create_texture_from_file: a glTF file with two meshes and PNG maps, written here,
     drawn through the file-taking entry points, equals the oracle's frame of the arrays they were made of."""

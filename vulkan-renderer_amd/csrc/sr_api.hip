@@ -97,6 +97,7 @@ struct sr_device_t {
     uint32_t cull_epoch = 0;
     uint32_t cull_min_chunks = 8;                  // meshes of fewer chunks are not worth the extra launch (SR_CULL_MIN_CHUNKS)
     bool cull_enabled = true;                      // SR_NO_CULL=1 turns it off
+    uint32_t direct_max_triangles = 500000;         // pending triangles of a draw (all its views) up to which it skips the tile path (SR_DIRECT_MAX_TRIANGLES; 0: never)
 };
 
 struct sr_mesh_t {
@@ -148,6 +149,12 @@ struct sr_target_t {
     // draw is issued again in full before anything of it can be observed (finish_target), like a draw whose tile
     // reference list overflowed.
     bool lean = false;
+    // A frame that leaves a FEW triangles pending (the reference's own 800 x 600 frame) is issued the same way plus one kernel that
+    // resolves the pending triangles straight into the visibility buffer (`direct`), and the near-plane clipper if the previous
+    // draw listed anything (`direct_clip`): two or three launches in place of the tile path's five.  Falls back like a lean draw.
+    bool direct = false, direct_clip = false;
+    uint32_t direct_expected = 0;  // pending triangles per view of the previous draw: sizes the direct rasteriser's launch
+    bool direct_banned = false;    // a direct draw of this mesh met a triangle too large for it: the tile path until the mesh changes
     bool normal_mapping = false;   // as the device said when the draw was issued (a redraw repeats it)
     bool no_alloc = false;      // the last draw came through sr_draw_no_alloc: if it is issued again, then the same way
 };
@@ -402,7 +409,9 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
         if (tg->lean) {   // the shading pass reports the counters of the pass
+            if (tg->direct && tg->direct_clip) launch_near_clip(st, m->d_idx, m->n_tris, m->px, m->py, m->pz, d_views, g, clip, b, tg->d_vis, tg->flags, v0);
             if (ev) { SR_HIP(hipEventRecord(ev[5], st)); SR_HIP(hipEventRecord(ev[6], st)); }
+            if (tg->direct) launch_direct_raster(st, m->d_idx, m->n_tris, sp, g, b, tg->d_vis, tg->flags, v0, nv, tg->direct_expected);
         } else {
             // (before the scan kernel, which reports the counters to the host)
             launch_near_clip(st, m->d_idx, m->n_tris, m->px, m->py, m->pz, d_views, g, clip, b, tg->d_vis, tg->flags, v0);
@@ -439,20 +448,22 @@ int finish_target(sr_device_t* dev, sr_target_t* tg)
     SR_HIP(hipStreamSynchronize(dev->stream));
     if (!tg->check_pending) return SR_OK;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0, clipped = 0, listed = 0;
+        uint64_t worst = 0, total = 0, unproj = 0, binned = 0, micro = 0, clipped = 0, listed = 0, too_big = 0;
         for (uint32_t p = 0; p < tg->passes; ++p) {
             const uint32_t* c = tg->h_counters + (size_t)p * kCountersPerPass;
-            worst = std::max<uint64_t>(worst, c[0]); total += c[0]; unproj += c[2]; binned += c[3]; micro += c[4];
+            worst = std::max<uint64_t>(worst, c[0]); total += c[0]; too_big += c[1]; unproj += c[2]; binned += c[3]; micro += c[4];
             listed += c[5]; clipped += c[6];
         }
         tg->total_refs = total; tg->unprojectable = unproj; tg->binned = binned; tg->micro = micro; tg->clipped = clipped;
-        const bool lean_missed = tg->lean && (binned > 0 || listed > 0);    // drawn without the kernels it turned out to need
+        // drawn without the kernels it turned out to need: pending triangles without the direct rasteriser (or some too large for it),
+        // clip-listed ones without the clipper
+        const bool lean_missed = tg->lean && ((binned > 0 && !tg->direct) || too_big > 0 || (listed > 0 && !(tg->direct && tg->direct_clip)));
         if (tg->no_alloc && listed > tg->clip_capacity_at_draw)   // the header promises sr_draw's frame or an error, never a frame with triangles missing
             return fail(SR_ERR_UNSUPPORTED, "sr_draw_no_alloc: " + std::to_string(listed) + " triangles cross the near plane or the guard band, the clip list of this entry point holds " +
                                                 std::to_string(tg->clip_capacity_at_draw) + " (use sr_draw)");
         if (!lean_missed && worst <= tg->capacity_at_draw) { tg->check_pending = false; return SR_OK; }
         if (attempt == 2) break;
-        if (lean_missed) { tg->lean = false; ++dev->counts.lean_redraws; }
+        if (lean_missed) { tg->direct_banned = tg->direct_banned || too_big > 0; tg->lean = tg->direct = tg->direct_clip = false; ++dev->counts.lean_redraws; }
         else if (tg->no_alloc) return fail(SR_ERR_UNSUPPORTED, "sr_draw_no_alloc: the frame needs " + std::to_string(worst) + " tile references, the static scratch holds " +
                                                                     std::to_string(tg->capacity_at_draw) + " after this draw's other buffers (use sr_draw)");
         else { dev->ref_capacity = std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFFFull); ++dev->counts.overflow_redraws; }
@@ -545,6 +556,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* v = std::getenv("SR_FILL_BLOCKS")) dev->fill_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = a workgroup always takes all views
     if (const char* v = std::getenv("SR_CULL_MIN_CHUNKS")) dev->cull_min_chunks = (uint32_t)std::max(1, std::atoi(v));   // tests: cull small meshes too
     if (std::getenv("SR_NO_CULL")) dev->cull_enabled = false;
+    if (const char* v = std::getenv("SR_DIRECT_MAX_TRIANGLES")) dev->direct_max_triangles = (uint32_t)std::max(0, std::atoi(v));
     if (const char* v = std::getenv("SR_STAGED_MIN_BLOCKS")) dev->staged_min_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = the staged resolve for small launches too
     if (const char* v = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 20;   // small budgets: many passes per draw
     *out = dev;
@@ -914,12 +926,23 @@ static int draw_common(sr_device dev, sr_target target, sr_mesh mesh, const void
     {   // lean or full (see sr_target_t::lean): from the counters of this target's previous draw.  They live in pinned
         // memory the kernels write; that draw may still be in flight, in which case the figures are a frame older --
         // either way only speed depends on them.
-        bool lean = target->passes > 0 && target->mesh == mesh && target->views.size() == n_views && std::getenv("SR_NO_LEAN") == nullptr;
-        for (uint32_t p = 0; lean && p < target->passes; ++p) {
+        const bool history = target->passes > 0 && target->mesh == mesh && target->views.size() == n_views && std::getenv("SR_NO_LEAN") == nullptr &&
+                             !dev->normal_mapping;   // (the kernel that reports a lean draw's counters has no normal-mapping form)
+        uint64_t binned = 0, listed = 0, refs = 0;
+        for (uint32_t p = 0; history && p < target->passes; ++p) {
             const volatile uint32_t* c = target->h_counters + (size_t)p * kCountersPerPass;
-            lean = c[3] == 0u && c[5] == 0u;
+            refs += c[0]; binned += c[3]; listed += c[5];
         }
-        target->lean = lean && !dev->normal_mapping;   // (the kernel that reports a lean draw's counters has no normal-mapping form)
+        const bool was_direct = target->direct;
+        if (target->mesh != mesh) target->direct_banned = false;
+        target->lean = history && binned == 0 && listed == 0;
+        // few pending triangles, and small ones -- a previous draw through the tile path says so by its references per triangle, one through
+        // the direct rasteriser by not having been repeated
+        target->direct_expected = (uint32_t)std::min<uint64_t>(binned / std::max(n_views, 1u) + 1, 0xFFFFFFFFull);
+        target->direct = history && !target->lean && dev->direct_max_triangles > 0 && binned <= dev->direct_max_triangles &&
+                         (was_direct || refs <= 4 * binned) && !target->direct_banned;
+        target->direct_clip = target->direct && listed > 0;
+        if (target->direct) target->lean = true;       // (issued like a lean draw, plus the direct rasteriser)
     }
     target->normal_mapping = dev->normal_mapping;
     target->mesh = mesh; target->mesh_verts = mesh->n_verts; target->mesh_tris = mesh->n_tris;
@@ -938,6 +961,7 @@ static int draw_common(sr_device dev, sr_target target, sr_mesh mesh, const void
     target->no_alloc = no_alloc;
     ++dev->counts.draws;
     if (target->lean) ++dev->counts.lean_draws;
+    if (target->direct) ++dev->counts.direct_draws;
     return issue_draw(dev, target);
 }
 

@@ -253,6 +253,7 @@ enum : uint32_t {
     kCtrUnprojectable = 2, // triangles that would need clipping and could not be clipped (clip list full, degenerate projection)
     kCtrClipListed = 7,    // triangles put on the clip list by set-up (may exceed its capacity)
     kCtrClipped = 8,       // triangles the near-plane clipper cut and drew
+    kCtrDirectTooBig = 9,  // pending triangles the direct rasteriser left alone because their boxes are too large for it (the draw is then repeated with the tile path)
     kNumPassCounters = 16,
 };
 constexpr uint32_t kPendingTotalStride = 32;   // words between the pending-list lengths of two views

@@ -917,7 +917,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__
         // stream has been synchronised): total references, -, unprojectable, binned, direct, -, clipped
         uint32_t binned = 0;
         for (uint32_t v = 0; v < n_views; ++v) binned += pending_total[v * kPendingTotalStride];
-        host_counters[0] = carry; host_counters[1] = 0u; host_counters[2] = counters[kCtrUnprojectable];
+        host_counters[0] = carry; host_counters[1] = counters[kCtrDirectTooBig]; host_counters[2] = counters[kCtrUnprojectable];
         host_counters[3] = binned; host_counters[4] = s_micro_total; host_counters[5] = counters[kCtrClipListed];
         host_counters[6] = counters[kCtrClipped];
     }
@@ -970,18 +970,24 @@ struct LaneTri {
     uint32_t tri;
 };
 
+// one sample s of pixel (x, y): coverage by the 64-bit edge functions, depth, 64-bit minimum into `word`
+template <int S>
+__device__ inline bool raster_sample(const TriSetup& ts, uint32_t tri, int x, int y, int s, unsigned long long* word)   // true: a depth went into `word`
+{
+    const int64_t px = (int64_t)x * kSubpix + sample_dx(S, s), py = (int64_t)y * kSubpix + sample_dy(S, s);
+    int64_t Ea, Eb, Ec;
+    edge_eval(ts, px, py, Ea, Eb, Ec);
+    if (((Ea + ts.bias_a) | (Eb + ts.bias_b) | (Ec + ts.bias_c)) < 0) return false;
+    uint64_t key;
+    if (!depth_key(ts, Ea, Eb, Ec, tri, key)) return false;
+    atomicMin(word, (unsigned long long)key);
+    return true;
+}
 template <int S>
 __device__ inline void raster_pixel(const TriSetup& ts, uint32_t tri, int x, int y, unsigned long long* cell /* S words */)
 {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int64_t px = (int64_t)x * kSubpix + sample_dx(S, s), py = (int64_t)y * kSubpix + sample_dy(S, s);
-        int64_t Ea, Eb, Ec;
-        edge_eval(ts, px, py, Ea, Eb, Ec);
-        if (((Ea + ts.bias_a) | (Eb + ts.bias_b) | (Ec + ts.bias_c)) < 0) continue;
-        uint64_t key;
-        if (depth_key(ts, Ea, Eb, Ec, tri, key)) atomicMin(cell + s, (unsigned long long)key);
-    }
+    for (int s = 0; s < S; ++s) (void)raster_sample<S>(ts, tri, x, y, s, cell + s);
 }
 
 // Same arithmetic in 32 bits, valid when the triangle's bounding box is under 64 pixels on both axes:
@@ -990,21 +996,25 @@ __device__ inline void raster_pixel(const TriSetup& ts, uint32_t tri, int x, int
 __device__ inline bool fits_32bit(const TriSetup& ts) { return (ts.maxX - ts.minX) < 16384 && (ts.maxY - ts.minY) < 16384; }
 
 template <int S>
+__device__ inline bool raster_sample32(const TriSetup& ts, uint32_t tri, int x, int y, int s, unsigned long long* word)   // true: a depth went into `word`
+{
+    const int32_t px = x * kSubpix + sample_dx(S, s), py = y * kSubpix + sample_dy(S, s);
+    const int32_t Ea = mul_small(ts.cx - ts.bx, py - ts.by) - mul_small(ts.cy - ts.by, px - ts.bx);
+    const int32_t Eb = mul_small(ts.ax - ts.cx, py - ts.cy) - mul_small(ts.ay - ts.cy, px - ts.cx);
+    const int32_t Ec = mul_small(ts.bx - ts.ax, py - ts.ay) - mul_small(ts.by - ts.ay, px - ts.ax);
+    if (((Ea + ts.bias_a) | (Eb + ts.bias_b) | (Ec + ts.bias_c)) < 0) return false;
+    const float l0 = (float)Ea * ts.rA, l2 = (float)Eb * ts.rA, l1 = (float)Ec * ts.rA;
+    float z = fmaf(l2, ts.z2, fmaf(l1, ts.z1, l0 * ts.z0));
+    z = z + 0.0f;
+    if (!(z >= 0.0f && z < 1.0f)) return false;
+    atomicMin(word, ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
+    return true;
+}
+template <int S>
 __device__ inline void raster_pixel32(const TriSetup& ts, uint32_t tri, int x, int y, unsigned long long* cell /* S words */)
 {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int32_t px = x * kSubpix + sample_dx(S, s), py = y * kSubpix + sample_dy(S, s);
-        const int32_t Ea = mul_small(ts.cx - ts.bx, py - ts.by) - mul_small(ts.cy - ts.by, px - ts.bx);
-        const int32_t Eb = mul_small(ts.ax - ts.cx, py - ts.cy) - mul_small(ts.ay - ts.cy, px - ts.cx);
-        const int32_t Ec = mul_small(ts.bx - ts.ax, py - ts.ay) - mul_small(ts.by - ts.ay, px - ts.ax);
-        if (((Ea + ts.bias_a) | (Eb + ts.bias_b) | (Ec + ts.bias_c)) < 0) continue;
-        const float l0 = (float)Ea * ts.rA, l2 = (float)Eb * ts.rA, l1 = (float)Ec * ts.rA;
-        float z = fmaf(l2, ts.z2, fmaf(l1, ts.z1, l0 * ts.z0));
-        z = z + 0.0f;
-        if (!(z >= 0.0f && z < 1.0f)) continue;
-        atomicMin(cell + s, ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)tri);
-    }
+    for (int s = 0; s < S; ++s) (void)raster_sample32<S>(ts, tri, x, y, s, cell + s);
 }
 
 template <int TL2, int S, int TPB>
@@ -1144,6 +1154,66 @@ __global__ __launch_bounds__(TPB) void raster_kernel(const uint32_t* __restrict_
         const int prev_bid = __shfl_up(covered ? bid : -1, 1);
         if (covered && (lane == 0u || prev_bid != bid)) flags.flags[(size_t)(view0 + view) * flags.nbx * flags.nby + bid] = 1u;
     }
+}
+
+// =================================================================================================
+// stage 3, small frames: the pending triangles resolved straight into the visibility buffer
+// =================================================================================================
+// The tile path (binning, scan, fill, one workgroup per tile) is four dependent launches, each a chain of dependent loads: some 90 us
+// on the reference's own 800 x 600 frame of 15 000 triangles, whatever little they have to do.  When a target's previous draw left
+// few triangles pending, the next one resolves them with this kernel instead: one wave per pending triangle, the clipped box walked
+// in steps of 64 samples (8 x 8 pixels at one sample, 8 x 2 pixels x 4 samples at four: neighbouring lanes are neighbouring words of
+// the visibility buffer, so a step's atomic minimums touch few lines), the same edge functions, depth expression and 64-bit minimum
+// as every other path.  A triangle whose box is larger than kDirectMaxBoxPixels is left alone and counted: the host then repeats the
+// draw with the tile path before anything of it can be observed (a wave would walk a screen-filling triangle for a millisecond).
+constexpr int kDirectMaxBoxPixels = 64 * 64;
+template <int S>
+__global__ __launch_bounds__(256) void direct_raster_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp, FrameGeom g, BinBuffers b,
+                                                            unsigned long long* __restrict__ vis, BlockFlags flags, uint32_t view0)
+{
+    const uint32_t view = blockIdx.y, lane = lane_id();
+    const uint32_t n_pending = min(b.pending_total[view * kPendingTotalStride], b.pending_stride);
+    const uint32_t* list = b.pending + (size_t)view * b.pending_stride;
+    const int2* xy = sp.xy + (size_t)view * sp.stride;
+    const float* zp = sp.z + (size_t)view * sp.stride;
+    unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
+    constexpr int kStepH = S == 1 ? 8 : 2;                         // a step is 8 pixels wide and kStepH tall
+    const int lx = S == 1 ? (int)(lane & 7u) : (int)((lane >> 2) & 7u), ly = S == 1 ? (int)(lane >> 3) : (int)(lane >> 5), ls = S == 1 ? 0 : (int)(lane & 3u);
+    uint32_t too_big = 0;
+    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_pending; i += gridDim.x * 4u) {     // the same triangle for the whole wave
+        const uint32_t tri = list[i];
+        if (tri >= n_tris) continue;   // (the list only ever holds valid ids; cheap insurance against a fault)
+        const uint32_t i0 = idx[3 * (size_t)tri], i1 = idx[3 * (size_t)tri + 1], i2 = idx[3 * (size_t)tri + 2];
+        const int2 a0 = xy[i0], a1 = xy[i1], a2 = xy[i2];
+        ScreenVertex v0, v1, v2;
+        v0.X = a0.x; v0.Y = a0.y; v0.z = zp[i0]; v0.rw = a0.x == kBadVertexX ? 0.0f : 1.0f;
+        v1.X = a1.x; v1.Y = a1.y; v1.z = zp[i1]; v1.rw = a1.x == kBadVertexX ? 0.0f : 1.0f;
+        v2.X = a2.x; v2.Y = a2.y; v2.z = zp[i2]; v2.rw = a2.x == kBadVertexX ? 0.0f : 1.0f;
+        TriSetup ts;
+        if (setup_triangle(v0, v1, v2, ts) != 1) continue;          // (set-up established: projectable, front-facing)
+        int x0, x1, y0, y1;
+        pixel_span<S>(ts.minX, ts.maxX, x0, x1);
+        pixel_span<S>(ts.minY, ts.maxY, y0, y1);
+        x0 = max(x0, g.rx); x1 = min(x1, g.rx + g.rw - 1);
+        y0 = max(y0, g.ry); y1 = min(y1, g.ry + g.rh - 1);
+        if (x0 > x1 || y0 > y1) continue;
+        if ((x1 - x0 + 1) > kDirectMaxBoxPixels / (y1 - y0 + 1)) { ++too_big; continue; }   // (the same for every lane of the wave)
+        const bool narrow = fits_32bit(ts);
+        for (int by = y0; by <= y1; by += kStepH)
+            for (int bx = x0; bx <= x1; bx += 8) {
+                const int x = bx + lx, y = by + ly;
+                bool wrote = false;
+                if (x <= x1 && y <= y1) {
+                    unsigned long long* word = &vis_view[((size_t)(y - g.ry) * g.rw + (x - g.rx)) * S + ls];
+                    wrote = narrow ? raster_sample32<S>(ts, tri, x, y, ls, word) : raster_sample<S>(ts, tri, x, y, ls, word);
+                }
+                // a step that wrote anything: the blocks under its four corners (all the blocks it reaches into) may hold something now
+                // (every lane of the wave is here: the triangle and the loop bounds are the wave's)
+                if (__ballot(wrote) != 0ull && lane < 4u)
+                    flags.of(view0 + view, min(bx + 7 * (int)(lane & 1u), x1) - g.rx, min(by + (kStepH - 1) * (int)(lane >> 1), y1) - g.ry) = 1u;
+            }
+    }
+    if (lane == 0u && too_big) atomicAdd(&b.counters[kCtrDirectTooBig], too_big);
 }
 
 // =================================================================================================
@@ -1698,7 +1768,7 @@ __device__ inline void report_pass(const PassReport& r, uint32_t lane)
         uint32_t binned = 0;
         for (uint32_t v = 0; v < r.n_views; ++v) binned += r.pending_total[v * kPendingTotalStride];
         uint32_t* h = r.host_counters;
-        h[0] = 0u; h[1] = 0u; h[2] = r.counters[kCtrUnprojectable]; h[3] = binned; h[4] = micro;
+        h[0] = 0u; h[1] = r.counters[kCtrDirectTooBig]; h[2] = r.counters[kCtrUnprojectable]; h[3] = binned; h[4] = micro;
         h[5] = r.counters[kCtrClipListed]; h[6] = r.counters[kCtrClipped];
     }
 }
@@ -2099,6 +2169,17 @@ void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, cons
     // the list is empty in any ordinary frame; five hundred waves share the pieces of a long one
     if (g.samples == 1) near_clip_kernel<1><<<128, 256, 0, st>>>(idx, n_tris, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, flags, view0);
     else near_clip_kernel<4><<<128, 256, 0, st>>>(idx, n_tris, px, py, pz, views, g, clip, b.counters, (unsigned long long*)vis, flags, view0);
+}
+
+void launch_direct_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
+                          uint64_t* vis, const BlockFlags& flags, uint32_t view0, uint32_t n_views, uint32_t expected_per_view)
+{
+    if (!n_tris || !n_views) return;
+    // about one wave per pending triangle, going by what the previous draw left pending (a wave's triangle is a chain of three dependent
+    // loads before any work: waves that take several in turn pay it several times); every wave takes triangles until the view's list is through
+    const dim3 grid(std::min(std::max((expected_per_view + 3u) / 4u, 64u), 4096u), n_views);
+    if (g.samples == 1) direct_raster_kernel<1><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, flags, view0);
+    else direct_raster_kernel<4><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, (unsigned long long*)vis, flags, view0);
 }
 
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters)

@@ -59,6 +59,9 @@ void launch_chunk_cull(hipStream_t st, const ChunkCull& cc, const CullView& v, c
 void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const float* px, const float* py, const float* pz,
                       const ViewXform* views, const FrameGeom& g, const ClipList& clip, const BinBuffers& b, uint64_t* vis, const BlockFlags& flags,
                       uint32_t view0);
+// the pending triangles of a draw issued without the tile path, resolved straight into the visibility buffer (a few thousand of them)
+void launch_direct_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
+                          uint64_t* vis, const BlockFlags& flags, uint32_t view0, uint32_t n_views, uint32_t expected_per_view);
 void launch_scan(hipStream_t st, const BinBuffers& b, uint32_t n_entries, uint32_t n_views, uint32_t* host_counters);
 void launch_fill(hipStream_t st, const FrameGeom& g, const BinBuffers& b, uint32_t n_tris, uint32_t n_views);
 void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g, const BinBuffers& b,
