@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--max-anisotropy", type=float, default=1.0, help="maxAnisotropy of the samplers of the timed run (1: trilinear; the reference's own sampler has 16)")
     ap.add_argument("--lib", default=None, help="time another build of the library (tools/exp_build.py) instead of the shipped one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline loop and the per-stage pass: no moving-camera figures, no 16x-anisotropic "
+                                                                  "second figure, no CPU baseline (profiling runs: every launch in the trace is a launch of the headline frame)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -454,7 +456,7 @@ def main():
             # (per_gpu_Mtris_per_s) is what it measures
             out["scaling_note"] = (f"weak scaling by view, no collective: the N=1 point of this series is `python bench.py --workload {workload}` "
                                    "(each entry of per_gpu_Mtris_per_s is one GPU's rate on its share); the default N=1 line is the c3_4k_10Mtri headline, another workload")
-        if world == 1 and views == 1:
+        if world == 1 and views == 1 and not args.headline_only:
             # The same draw under a moving camera (the reference's own use: an orbit driven by the keys, src/main.cpp:223-267, the block
             # rewritten every frame, :988-1004): the eye advances one degree along the orbit every step, and, second figure, jumps a third
             # of the way round it every step.  The timed loop above redraws one camera; what it leans on from frame to frame (lean
@@ -479,7 +481,7 @@ def main():
             out["ms_per_step_camera_jumps"] = round(jump_ms, 4)
             out["moving_camera"] = {"orbit": dict(orbit_counts, step_degrees=1), "jumps": dict(jump_counts, step_degrees=127),
                                     "note": "draws / lean_draws / lean_redraws / overflow_redraws of the timed steps; a lean redraw is a frame that had to be issued a second time in full"}
-        if world == 1 and args.max_anisotropy <= 1.0:
+        if world == 1 and args.max_anisotropy <= 1.0 and not args.headline_only:
             # the same frame through the sampler the reference creates (maxAnisotropy 16): a second figure, not the headline
             tex16 = [sr.create_texture(dev, im, sampler=sr.default_sampler(16.0)) if im is not None else None for im in images]
             sr.draw(dev, tgt, mesh, ubo, tex16)
@@ -487,7 +489,7 @@ def main():
             for t in tex16:
                 if t is not None:
                     t.destroy()
-        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: the other ranks would sit in the final barrier meanwhile
+        if not args.no_cpu_baseline and not args.headline_only and world == 1:   # reported at N=1 only: the other ranks would sit in the final barrier meanwhile
             from oracle import oracle
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             oracle.set_anisotropic(args.max_anisotropy > 1.0)
