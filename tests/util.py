@@ -29,14 +29,19 @@ def color_match_fraction(a, b, tol=1):
     return float((d <= tol).mean()), int(d.max())
 
 
-def gpu_render(sr, device, verts, idx, images, ubos, width, height, samples=1, rect=None, textures=None):
-    """Draw through the C ABI and read everything back.  Returns a list of per-view dicts."""
+def gpu_render(sr, device, verts, idx, images, ubos, width, height, samples=1, rect=None, textures=None, draws=None):
+    """Draw through the C ABI and read everything back.  Returns a list of per-view dicts.  draws (default: SR_TEST_DRAWS or 1):
+    how often the frame is drawn into the target before it is read -- a second draw takes the paths that go by the first one's
+    counters (lean draws, the direct rasteriser)."""
+    import os
+    draws = draws or int(os.environ.get("SR_TEST_DRAWS", "1"))
     ubos = np.atleast_2d(np.asarray(ubos, np.float32))
     mesh = sr.create_mesh_from_data(device, verts, idx)
     tex = textures if textures is not None else [sr.create_texture(device, im) for im in images]
     tgt = sr.RenderTarget(device, width, height, samples=samples, n_views=ubos.shape[0], rect=rect)
     try:
-        sr.draw(device, tgt, mesh, ubos, tex)
+        for _ in range(draws):
+            sr.draw(device, tgt, mesh, ubos, tex)
         out = [{"tri": tgt.read_triangle_ids(v), "depth": tgt.read_depth(v), "bgra": tgt.read_color(v), "vis": tgt.read_visibility(v)}
                for v in range(ubos.shape[0])]
         stats = tgt.stats()
