@@ -133,7 +133,7 @@ def main():
         lowest, clipped, dropped = check_seed(seed, sr, oracle, dev, util, vertex_stage_too=seed % 4 == 0)
         worst_frac = min(worst_frac, lowest)
         total_clipped += clipped; total_dropped += dropped
-        if on_gpu and (seed - first) % 200 == 199:
+        if on_gpu and (seed - first) % 50 == 49:
             print(f"... through seed {seed}, lowest colour fraction so far {worst_frac:.5f}", flush=True)
     print(f"ok: seeds {first}..{first + count - 1} on {'the GPU' if on_gpu else 'the CPU execution of the kernels'}, lowest colour fraction on well-covered frames {worst_frac:.5f}"
           f"; near-plane clipper: {total_clipped} triangles clipped, {total_dropped} given up")

@@ -749,7 +749,8 @@ def test_chunks_outside_a_band_are_skipped_and_the_band_stays_the_same(sr, oracl
                 a = util.gpu_render(sr, culling, verts, idx, images, ubo, W, H, 1, rect=rect)[0]
                 b = util.gpu_render(sr, plain, verts, idx, images, ubo, W, H, 1, rect=rect)[0]
                 assert np.array_equal(a["vis"], b["vis"]) and np.array_equal(a["bgra"], b["bgra"]), (k, rect)
-                assert {x: y for x, y in a["stats"].items() if x != "passes"} == {x: y for x, y in b["stats"].items() if x != "passes"}, (k, rect)
+                path_dependent = ("passes", "tile_refs")      # (a repeat of a draw takes the tile path or not by counters that may not have arrived yet)
+                assert {x: y for x, y in a["stats"].items() if x not in path_dependent} == {x: y for x, y in b["stats"].items() if x not in path_dependent}, (k, rect)
                 _check_view(a, oracle.draw(ubo, verts, idx, images, W, H, 1, rect=rect, threads=4))
             after = culling.draw_counts()
             tested, culled = after["chunks_tested"] - before["chunks_tested"], after["chunks_culled"] - before["chunks_culled"]
