@@ -766,6 +766,55 @@ def test_chunks_outside_a_band_are_skipped_and_the_band_stays_the_same(sr, oracl
         culling.close(); plain.close()
 
 
+@pytest.mark.parametrize("samples", [1, 4])
+def test_lean_view_batches_store_no_depth_plane(sr, oracle, samples):
+    """A lean draw of more views than travel as kernel arguments stores no depth plane in its vertex stage; set-up works out the depths
+    of the triangles that cover a sample again, with the vertex stage's own operations.  Eleven views of a sphere of sub-pixel
+    triangles, drawn three times from moving cameras (the second and third draw are lean): workgroups that take one view each, workgroups
+    that loop over the views, a scratch budget that splits the batch into passes -- every view equals the oracle's and the same draw by
+    a device that keeps the plane, bit for bit."""
+    W, H = (192, 108) if samples == 1 else (96, 54)     # (at four samples a micro-triangle's box holds 8 pixels at most)
+    n_views = 11
+    verts, idx = sr.scene.uv_sphere(200, 150)
+    half = verts[::2, :3]
+    half[half == 0.0] = -0.0          # (zeros of both signs among the coordinates)
+    verts[::2, :3] = half
+    images = sr.scene.material_textures(32, seed=2)
+    devices = {"default": util.device_with_env(sr), "looping": util.device_with_env(sr, SR_FILL_BLOCKS="1"),
+               "passes": util.device_with_env(sr, SR_SCRATCH_MIB="2"), "stored": util.device_with_env(sr, SR_STORE_DEPTH="1")}
+    try:
+        tex = {k: [sr.create_texture(d, im) for im in images] for k, d in devices.items()}
+        mesh = {k: sr.create_mesh_from_data(d, verts, idx) for k, d in devices.items()}
+        tgt = {k: sr.RenderTarget(d, W, H, samples=samples, n_views=n_views) for k, d in devices.items()}
+        cams = sr.scene.orbit_ubos(n_views + 2, W, H)
+        c, s_ = np.cos(0.7), np.sin(0.7)
+        turned = np.array([[0.9 * c, -0.9 * s_, 0, 0.05], [0.9 * s_, 0.9 * c, 0, -0.02], [0, 0, 0.9, 0.03], [0, 0, 0, 1]], np.float32)   # a model matrix that is not the identity
+        for k in range(3):
+            u = cams[k:k + n_views].copy()
+            for v in (3, 7):
+                u[v] = sr.scene.make_ubo(turned, sr.scene.look_at((2.0, 2.0, 2.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0)), sr.scene.perspective(np.radians(45.0), W / H, 0.1, 10.0), (2.0, 2.0, 2.0))
+            for name, d in devices.items():
+                sr.draw(d, tgt[name], mesh[name], u, tex[name])
+            got = {name: [{"tri": tgt[name].read_triangle_ids(v), "depth": tgt[name].read_depth(v), "bgra": tgt[name].read_color(v)} for v in range(n_views)]
+                   for name in devices}
+            for v in range(n_views):
+                _check_view(got["default"][v], oracle.draw(u[v], verts, idx, images, W, H, samples, threads=4))
+                for name in ("looping", "passes", "stored"):
+                    for key in ("tri", "depth", "bgra"):
+                        assert np.array_equal(got[name][v][key], got["default"][v][key]), (k, v, name, key)
+            stats = {name: tgt[name].stats() for name in devices}
+            assert stats["default"]["triangles_binned"] == 0 and stats["default"]["triangles_clipped"] == 0      # nothing pending: the repeats are lean
+            assert stats["passes"]["passes"] > 1
+            for name in ("looping", "stored"):
+                assert stats[name] == stats["default"], (k, name)
+        for name, d in devices.items():
+            c = d.draw_counts()
+            assert c["lean_draws"] == 2 and c["lean_redraws"] == 0, (name, c)
+    finally:
+        for d in devices.values():
+            d.close()
+
+
 def test_staged_resolve_gives_the_same_frames(sr, oracle, device):
     """A one-sample, one-view set-up launch of thousands of workgroups resolves its micro-triangles' samples through LDS (marked per lane,
     numbered per wave, resolved by whole waves); smaller launches resolve inside each lane's walk.  Forced on for small launches

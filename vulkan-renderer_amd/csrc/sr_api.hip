@@ -97,6 +97,7 @@ struct sr_device_t {
     uint32_t cull_epoch = 0;
     uint32_t cull_min_chunks = 8;                  // meshes of fewer chunks are not worth the extra launch (SR_CULL_MIN_CHUNKS)
     bool cull_enabled = true;                      // SR_NO_CULL=1 turns it off
+    bool recompute_depth = true;                    // lean draws of view batches store no depth plane (SR_STORE_DEPTH=1: always store it)
     uint32_t direct_max_triangles = 500000;         // pending triangles of a draw (all its views) up to which it skips the tile path (SR_DIRECT_MAX_TRIANGLES; 0: never)
 };
 
@@ -224,15 +225,15 @@ constexpr size_t kPlaneBytesPerVertex = sizeof(int2) + sizeof(float);
 
 // per-view scratch bytes of a pass.  A lean draw launches no binning kernel and so needs no binning records, by far the largest
 // buffer (48 of 64 bytes per triangle): its passes take several times as many views, and a pass reads the mesh once.
-size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g, bool lean)
+size_t per_view_bytes(const sr_mesh_t* m, const FrameGeom& g, bool lean, bool depth_plane)
 {
-    return (size_t)plane_stride(m->n_verts) * kPlaneBytesPerVertex + ((size_t)m->n_tris + 1024) * ((lean ? 0 : 4 * sizeof(BinRecord)) + 4) + (size_t)m->n_tris / 64 +
+    return (size_t)plane_stride(m->n_verts) * (depth_plane ? kPlaneBytesPerVertex : sizeof(int2)) + ((size_t)m->n_tris + 1024) * ((lean ? 0 : 4 * sizeof(BinRecord)) + 4) + (size_t)m->n_tris / 64 +
            (size_t)g.tiles_x * g.tiles_y * 16 + 64 + kPendingTotalStride * 4;
 }
 
-uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views, bool lean)
+uint32_t views_per_pass(const sr_device_t* dev, const sr_mesh_t* m, const FrameGeom& g, uint32_t n_views, bool lean, bool depth_plane)
 {
-    size_t pv = per_view_bytes(m, g, lean);
+    size_t pv = per_view_bytes(m, g, lean, depth_plane);
     uint64_t by_mem = std::max<uint64_t>(1, dev->scratch_budget / std::max<size_t>(pv, 1));
     uint64_t by_refs = std::max<uint64_t>(1, (uint64_t)0x7FFFFFFF / std::max<uint32_t>(m->n_tris, 1));
     uint64_t v = std::min<uint64_t>({(uint64_t)n_views, by_mem, by_refs, (uint64_t)65535});
@@ -253,7 +254,10 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     const FrameGeom& g = tg->g;
     const uint32_t n_views = (uint32_t)tg->views.size();
     const bool no_alloc = tg->no_alloc;
-    const uint32_t vpp = no_alloc ? n_views : views_per_pass(dev, m, g, n_views, tg->lean);
+    // A lean draw of a batch of views (more than travel as kernel arguments) stores no depth plane: of its kernels only set-up reads
+    // window-space depths, and only for the triangles that reach its second phase; it works them out again from the positions.
+    const bool depth_plane = !(tg->lean && !tg->direct && !no_alloc && dev->recompute_depth && n_views > kMaxPackedViews);
+    const uint32_t vpp = no_alloc ? n_views : views_per_pass(dev, m, g, n_views, tg->lean, depth_plane);
     const uint32_t passes = (n_views + vpp - 1) / vpp;
     const uint32_t n_tiles = (uint32_t)(g.tiles_x * g.tiles_y);
     hipStream_t st = dev->stream;
@@ -267,7 +271,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
     const size_t zero_words = (count_words + (size_t)vpp * kPendingTotalStride + kNumPassCounters + kMicroSpread * kMicroSpreadStride + 3) & ~(size_t)3;
     const size_t view_bytes = (size_t)n_views * sizeof(ViewXform);
     const uint32_t v_stride = std::max<uint32_t>(plane_stride(m->n_verts), 4);
-    const size_t bytes_screen = (size_t)vpp * v_stride * kPlaneBytesPerVertex;   // the int2 plane of every view of the pass, then the float plane
+    const size_t bytes_screen = (size_t)vpp * v_stride * (depth_plane ? kPlaneBytesPerVertex : sizeof(int2));   // the int2 plane of every view of the pass, then the float plane
     const size_t bytes_tile_count = (zero_words + (size_t)vpp * n_blocks) * 4;
     const size_t bytes_pending = (size_t)vpp * pending_stride * 4;
     const size_t bytes_tile_offset = ((size_t)vpp * n_tiles + 1) * 4;
@@ -337,7 +341,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
 
     ScreenPlanes sp{};
     sp.xy = (int2*)ps.screen;
-    sp.z = (float*)((char*)ps.screen + (size_t)vpp * v_stride * sizeof(int2));
+    sp.z = depth_plane ? (float*)((char*)ps.screen + (size_t)vpp * v_stride * sizeof(int2)) : nullptr;
     sp.stride = v_stride;
     BinBuffers b{};
     b.count_small = ps.tile_count;
@@ -403,8 +407,10 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (ev) SR_HIP(hipEventRecord(ev[1], st));
         if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr, dev->fill_blocks);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
+        const DepthSource depth_source{m->px, m->py, m->pz, d_views};
         launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, tg->flags, v0, ev ? ev[3] : nullptr, !tg->lean, dev->fill_blocks,
-                     fused ? cull_use.visible : nullptr /* (culled vertex groups were skipped by the fused vertex launch only) */, dev->staged_min_blocks);
+                     fused ? cull_use.visible : nullptr /* (culled vertex groups were skipped by the fused vertex launch only) */, dev->staged_min_blocks,
+                     depth_plane ? nullptr : &depth_source);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
@@ -556,6 +562,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* v = std::getenv("SR_FILL_BLOCKS")) dev->fill_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = a workgroup always takes all views
     if (const char* v = std::getenv("SR_CULL_MIN_CHUNKS")) dev->cull_min_chunks = (uint32_t)std::max(1, std::atoi(v));   // tests: cull small meshes too
     if (std::getenv("SR_NO_CULL")) dev->cull_enabled = false;
+    if (const char* v = std::getenv("SR_STORE_DEPTH")) dev->recompute_depth = std::atoi(v) == 0;
     if (const char* v = std::getenv("SR_DIRECT_MAX_TRIANGLES")) dev->direct_max_triangles = (uint32_t)std::max(0, std::atoi(v));
     if (const char* v = std::getenv("SR_STAGED_MIN_BLOCKS")) dev->staged_min_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = the staged resolve for small launches too
     if (const char* v = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 20;   // small budgets: many passes per draw

@@ -50,7 +50,7 @@ constexpr int32_t kBadVertexX = INT32_MIN;   // xy.x of a vertex that cannot be 
 __host__ __device__ inline uint32_t plane_stride(uint32_t n_verts) { return (n_verts + 3u) & ~3u; }
 struct ScreenPlanes {
     int2* xy;      // [views][stride]: window x, y in 1/256 pixel
-    float* z;      // [views][stride]: depth
+    float* z;      // [views][stride]: depth; null in a pass that stores none (launch_setup with a DepthSource)
     uint32_t stride;   // vertices per view in both planes: plane_stride(number of vertices)
 };
 
@@ -134,6 +134,21 @@ __device__ inline ScreenVertex project_vertex(const ViewXform& vx, float px, flo
     sv.rw = rw;
     return sv;
 }
+
+// the depth project_vertex stores for a vertex it can project, by the same operations in the same order (a pass whose vertex stage
+// stores no depth plane: set-up works it out again for the few triangles that cover a sample)
+__device__ inline float project_depth(const ViewXform& vx, float px, float py, float pz)
+{
+    float wp[4], clip[4];
+    mat4_mul_vec4(vx.model, px, py, pz, 1.0f, wp);
+    mat4_mul_vec4(vx.pv, wp[0], wp[1], wp[2], 1.0f, clip);
+    const float rw = 1.0f / clip[3];
+    return clip[2] * rw;
+}
+struct DepthSource {         // what project_depth needs: the mesh's position planes and the transforms of the pass
+    const float *px, *py, *pz;
+    const ViewXform* views;
+};
 
 // ---- triangle set-up -----------------------------------------------------------------------------
 // a = v0, b = v2, c = v1: a front-facing triangle (counter-clockwise on the displayed image) is

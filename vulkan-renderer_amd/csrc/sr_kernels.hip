@@ -130,7 +130,7 @@ __device__ inline void vertex_group(const Views& views, uint32_t view_begin, uin
         }
         const size_t o = (size_t)view * out.stride + G * (size_t)group;
         *reinterpret_cast<IV*>(out.xy + o) = xy.v;
-        *reinterpret_cast<FV*>(out.z + o) = z.v;
+        if (out.z) *reinterpret_cast<FV*>(out.z + o) = z.v;      // (the same for the whole launch)
     }
 }
 
@@ -404,11 +404,16 @@ __device__ inline T plane_at(const T* plane, uint32_t byte_offset)
 // one or two vertices that cannot be projected go on the clip list; whatever is left is handed to the
 // binning kernel through the view's pending list (ballots and prefix counts inside the block, one
 // atomic add per block that has any).
-template <int S, bool VIEW_LOOP, bool STAGED>
+// ZCALC: the pass has no depth plane (a lean draw of a batch of views: the plane is a third of what the vertex stage writes, and only the
+// triangles that reach phase two -- a few in a hundred of a mesh much finer than the frame -- ever read it); phase two works the three
+// depths out again from the positions, with the vertex stage's own operations.
+template <int S, bool VIEW_LOOP, bool STAGED, bool ZCALC = false>
 __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                     FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, BlockFlags flags,
-                                                    uint32_t view0, uint32_t n_views, uint32_t views_per_block, const uint32_t* __restrict__ chunk_visible)
+                                                    uint32_t view0, uint32_t n_views, uint32_t views_per_block, const uint32_t* __restrict__ chunk_visible,
+                                                    DepthSource ds)
 {
+    static_assert(!ZCALC || !STAGED, "depths are worked out again in the form of phase two that resolves inside the walk");
     // One barrier per view, between the two phases.  A wave that is through with a view goes on to the next while others still walk
     // the queue, so the queue exists twice (views alternate) and its counter three times: the counter of the next view is zeroed at the
     // top of a view, before the view's barrier -- its last readers finished two views ago and passed the previous barrier since, its
@@ -618,7 +623,13 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             if (q < n_q) {
                 const uint32_t t = s_q_tri[qb][q], j0 = s_q_i0[qb][q], j1 = s_q_i1[qb][q], j2 = s_q_i2[qb][q];
                 const int2 a0 = plane_at(xy, j0), a1 = plane_at(xy, j1), a2 = plane_at(xy, j2);
-                const float za = plane_at(zp, j0 >> 1), zb = plane_at(zp, j1 >> 1), zc = plane_at(zp, j2 >> 1);
+                float za, zb, zc;
+                if constexpr (ZCALC) {
+                    const ViewXform& vx = ds.views[view];
+                    za = project_depth(vx, plane_at(ds.px, j0 >> 1), plane_at(ds.py, j0 >> 1), plane_at(ds.pz, j0 >> 1));
+                    zb = project_depth(vx, plane_at(ds.px, j1 >> 1), plane_at(ds.py, j1 >> 1), plane_at(ds.pz, j1 >> 1));
+                    zc = project_depth(vx, plane_at(ds.px, j2 >> 1), plane_at(ds.py, j2 >> 1), plane_at(ds.pz, j2 >> 1));
+                } else { za = plane_at(zp, j0 >> 1); zb = plane_at(zp, j1 >> 1); zc = plane_at(zp, j2 >> 1); }
                 int x0, y0, npx, npy;
                 sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
                 const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
@@ -2124,7 +2135,7 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
     }
     // a large one: one launch per row (rows of one launch run into each other, which costs the 50 M-triangle batch 4 % of this kernel)
     for (uint32_t v = 0; v < n_views; v += views_per_block) {
-        ScreenPlanes o = out; o.xy += (size_t)v * out.stride; o.z += (size_t)v * out.stride;
+        ScreenPlanes o = out; o.xy += (size_t)v * out.stride; if (o.z) o.z += (size_t)v * out.stride;
         const uint32_t nv = std::min(views_per_block, n_views - v);
         vertex_kernel<<<dim3(grid_x, 1), 256, 0, st>>>(px, py, pz, n, views + v, nv, nv, W, H, o, debug_out ? debug_out + (size_t)v * n : nullptr,
                                                        clip_out ? (float4*)clip_out + (size_t)v * n : nullptr);
@@ -2137,9 +2148,18 @@ static inline uint32_t chunk_grid(const BinBuffers& b) { return std::min<uint32_
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags, uint32_t view0, hipEvent_t between,
-                  bool bin, uint32_t fill_blocks, const uint32_t* chunk_visible, uint32_t staged_min_blocks)
+                  bool bin, uint32_t fill_blocks, const uint32_t* chunk_visible, uint32_t staged_min_blocks, const DepthSource* depth_source)
 {
     if (!n_tris || !n_views) return;
+    if (depth_source) {   // no depth plane: the view-loop form, whatever the number of views per workgroup
+        const uint32_t gx = div_up(n_tris, kSetupBlockTris);
+        const uint32_t vpb = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * gx / std::max(fill_blocks, 1u)), 1u), n_views);
+        const dim3 grid(gx, div_up(n_views, vpb));
+        if (g.samples == 1) setup_kernel<1, true, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, vpb, nullptr, *depth_source);
+        else setup_kernel<4, true, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, vpb, nullptr, *depth_source);
+        if (between) (void)hipEventRecord(between, st);
+        return;           // (such a pass is a lean one: no binning)
+    }
     // a workgroup takes every view of the pass for its triangles, unless the mesh is too small to fill the chip that way
     const uint32_t grid_x = div_up(n_tris, kSetupBlockTris);
     const uint32_t views_per_block = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views);
@@ -2147,12 +2167,12 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
     if (views_per_block == 1) {
         // (the staged resolve where the launch is long enough to be bound by what it does, not by how long one workgroup takes)
         const bool staged = g.samples == 1 && (uint64_t)grid.x * grid.y >= staged_min_blocks;
-        if (staged) setup_kernel<1, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
-        else if (g.samples == 1) setup_kernel<1, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
-        else setup_kernel<4, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible);
+        if (staged) setup_kernel<1, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{});
+        else if (g.samples == 1) setup_kernel<1, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{});
+        else setup_kernel<4, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{});
     } else {
-        if (g.samples == 1) setup_kernel<1, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr);
-        else setup_kernel<4, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr);
+        if (g.samples == 1) setup_kernel<1, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr, DepthSource{});
+        else setup_kernel<4, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr, DepthSource{});
     }
     if (between) (void)hipEventRecord(between, st);
     if (!bin) return;

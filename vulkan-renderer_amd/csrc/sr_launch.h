@@ -50,7 +50,8 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags /* of the target */, uint32_t view0,
                   hipEvent_t between /* recorded between set-up and binning, may be null */, bool bin = true /* false: set-up only */,
                   uint32_t fill_blocks = kFillBlocks, const uint32_t* chunk_visible = nullptr /* chunk culling: one-view draws only */,
-                  uint32_t staged_min_blocks = kStagedResolveMinBlocks);
+                  uint32_t staged_min_blocks = kStagedResolveMinBlocks,
+                  const DepthSource* depth_source = nullptr /* set: sp.z is null, set-up works depths out itself; set-up only, no binning */);
 // chunk culling (sr_device.h): bounds of every chunk of setup_block_triangles() triangles, once per mesh; the per-draw test
 void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint2* vrange);
 void launch_chunk_cull(hipStream_t st, const ChunkCull& cc, const CullView& v, const FrameGeom& g);
