@@ -414,13 +414,18 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
                                                     DepthSource ds)
 {
     static_assert(!ZCALC || !STAGED, "depths are worked out again in the form of phase two that resolves inside the walk");
-    // One barrier per view, between the two phases.  A wave that is through with a view goes on to the next while others still walk
-    // the queue, so the queue exists twice (views alternate) and its counter three times: the counter of the next view is zeroed at the
-    // top of a view, before the view's barrier -- its last readers finished two views ago and passed the previous barrier since, its
-    // next writers are behind this one.
-    constexpr uint32_t kQueues = VIEW_LOOP ? 2u : 1u;
-    __shared__ uint32_t s_q_tri[kQueues][kSetupBlockTris], s_q_i0[kQueues][kSetupBlockTris], s_q_i1[kQueues][kSetupBlockTris], s_q_i2[kQueues][kSetupBlockTris];
-    __shared__ uint32_t s_q_count[3];
+    // The queue of phase two.  One view per workgroup: filled in phase one, a barrier, emptied in phase two.  In the view loop a view of
+    // a mesh much finer than the frame queues a few dozen triangles per workgroup -- half a wave's worth, and phase two would run for
+    // them at half a wave's width once per view.  So the queue is kept over the views (every entry carries its view) and emptied when
+    // it holds more than kDrainAt entries or the views are through: whole waves, all four of them.  One barrier per view (after the
+    // pushes) and one more after each emptying.  Two counters take the pushes of even and odd views in turn and are never reset: what a
+    // counter reads after a view's barrier is final until the view after the next one starts pushing, which no wave does before every
+    // wave has passed the next barrier -- so all waves derive the same queue length from it, and where the next view's entries go.
+    constexpr uint32_t kDrainAt = 512u;
+    constexpr uint32_t kQueueCap = VIEW_LOOP ? kSetupBlockTris + kDrainAt : kSetupBlockTris;     // (a view queues kSetupBlockTris entries at most)
+    __shared__ uint32_t s_q_tri[kQueueCap], s_q_i0[kQueueCap], s_q_i1[kQueueCap], s_q_i2[kQueueCap];
+    __shared__ uint32_t s_q_view[VIEW_LOOP ? kQueueCap : 1u];
+    __shared__ uint32_t s_q_count[2];
     // Staged resolve (STAGED: one sample, one view per workgroup, a launch of thousands of workgroups).  An atomic minimum costs what
     // the 128-byte lines its instruction touches cost (measured: 64 lanes in 4 lines 155 G operations/s, in 64 lines 25 G/s), and a
     // lane that walks its own box fires in a few of its turns only: instructions with a fifth of the lanes active, each in a line of
@@ -459,11 +464,11 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     // (VIEW_LOOP false = one view per workgroup: without the loop around it the code needs 63 registers instead of 90, which is worth
     // 5 % on a one-view frame of 10 M triangles)
     const uint32_t view_end = VIEW_LOOP ? min(view_begin + views_per_block, n_views) : view_begin + 1u;
-    if (tid < 3u) s_q_count[tid] = 0u;
+    if (tid < 2u) s_q_count[tid] = 0u;
     __syncthreads();
+    uint32_t q_seen0 = 0, q_seen1 = 0, q_total = 0;   // the two counters as last read after a barrier; entries in the queue (the same in every wave)
     for (uint32_t view = view_begin; view < view_end; ++view) {
-    const uint32_t turn_of_view = view - view_begin, qb = turn_of_view % kQueues, qc = turn_of_view % 3u;
-    if (VIEW_LOOP && tid == 0) s_q_count[(turn_of_view + 1u) % 3u] = 0u;
+    const uint32_t qp = VIEW_LOOP ? (view - view_begin) & 1u : 0u;
     const int2* xy = sp.xy + (size_t)view * sp.stride;
     int2 r0[kSetupTris], r1[kSetupTris], r2[kSetupTris];
 #pragma unroll
@@ -538,25 +543,32 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
 #pragma unroll
         for (uint32_t k = 0; k < kSetupTris; ++k) { qm[k] = __ballot(queued[k]); n += (uint32_t)__popcll(qm[k]); }
         uint32_t base = 0;
-        if (lane == 0 && n) base = atomicAdd(&s_q_count[qc], n);
-        base = (uint32_t)__shfl((int)base, 0);
+        if (lane == 0 && n) base = atomicAdd(&s_q_count[qp], n);
+        base = (uint32_t)__shfl((int)base, 0) - (qp ? q_seen1 : q_seen0) + q_total;
 #pragma unroll
         for (uint32_t k = 0; k < kSetupTris; ++k) {
             if (queued[k]) {
                 const uint32_t q = base + (uint32_t)__popcll(qm[k] & ((1ull << lane) - 1ull));
-                s_q_tri[qb][q] = tri[k]; s_q_i0[qb][q] = i0[k]; s_q_i1[qb][q] = i1[k]; s_q_i2[qb][q] = i2[k];
+                s_q_tri[q] = tri[k]; s_q_i0[q] = i0[k]; s_q_i1[q] = i1[k]; s_q_i2[q] = i2[k];
+                if constexpr (VIEW_LOOP) s_q_view[q] = view;
             }
             base += (uint32_t)__popcll(qm[k]);
         }
     }
     __syncthreads();
-    {
+    {   // (all the same in every wave)
+        const uint32_t cur = s_q_count[qp];
+        q_total += cur - (qp ? q_seen1 : q_seen0);
+        if (qp) q_seen1 = cur; else q_seen0 = cur;
+    }
+    if (!VIEW_LOOP || q_total > kDrainAt || view + 1u == view_end) {
         const float* zp = sp.z + (size_t)view * sp.stride;
         unsigned long long* vis_view = vis + (size_t)(view0 + view) * g.rw * g.rh * S;
-        const uint32_t n_q = s_q_count[qc];
+        const uint32_t n_q = q_total;
         for (uint32_t q0 = 0; q0 < n_q; q0 += 256u) {   // (the same number of turns for every work-item: the ballot below is reached by all)
             const uint32_t q = q0 + tid;
             bool drawn = false;
+            uint32_t qv = view;                         // the entry's view
             uint32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;   // blocks of flags the drawn triangle's box reaches into
             if constexpr (kStaged) {
                 uint32_t mask = 0, t = 0, inv = 0;
@@ -564,8 +576,8 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
                 MicroEdges e{};
                 float za = 0.0f, zb = 0.0f, zc = 0.0f, rA = 0.0f;
                 if (q < n_q) {
-                    t = s_q_tri[qb][q];
-                    const uint32_t j0 = s_q_i0[qb][q], j1 = s_q_i1[qb][q], j2 = s_q_i2[qb][q];
+                    t = s_q_tri[q];
+                    const uint32_t j0 = s_q_i0[q], j1 = s_q_i1[q], j2 = s_q_i2[q];
                     const int2 a0 = plane_at(xy, j0), a1 = plane_at(xy, j1), a2 = plane_at(xy, j2);
                     za = plane_at(zp, j0 >> 1); zb = plane_at(zp, j1 >> 1); zc = plane_at(zp, j2 >> 1);
                     sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
@@ -621,19 +633,27 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
                 }
             } else
             if (q < n_q) {
-                const uint32_t t = s_q_tri[qb][q], j0 = s_q_i0[qb][q], j1 = s_q_i1[qb][q], j2 = s_q_i2[qb][q];
-                const int2 a0 = plane_at(xy, j0), a1 = plane_at(xy, j1), a2 = plane_at(xy, j2);
+                const uint32_t t = s_q_tri[q], j0 = s_q_i0[q], j1 = s_q_i1[q], j2 = s_q_i2[q];
+                const int2* xy_q = xy;
+                const float* zp_q = zp;
+                unsigned long long* vis_q = vis_view;
+                if constexpr (VIEW_LOOP) {          // the planes and the visibility buffer of the entry's view
+                    qv = s_q_view[q];
+                    xy_q = sp.xy + (size_t)qv * sp.stride; zp_q = sp.z + (size_t)qv * sp.stride;
+                    vis_q = vis + (size_t)(view0 + qv) * g.rw * g.rh * S;
+                }
+                const int2 a0 = plane_at(xy_q, j0), a1 = plane_at(xy_q, j1), a2 = plane_at(xy_q, j2);
                 float za, zb, zc;
                 if constexpr (ZCALC) {
-                    const ViewXform& vx = ds.views[view];
+                    const ViewXform& vx = ds.views[qv];
                     za = project_depth(vx, plane_at(ds.px, j0 >> 1), plane_at(ds.py, j0 >> 1), plane_at(ds.pz, j0 >> 1));
                     zb = project_depth(vx, plane_at(ds.px, j1 >> 1), plane_at(ds.py, j1 >> 1), plane_at(ds.pz, j1 >> 1));
                     zc = project_depth(vx, plane_at(ds.px, j2 >> 1), plane_at(ds.py, j2 >> 1), plane_at(ds.pz, j2 >> 1));
-                } else { za = plane_at(zp, j0 >> 1); zb = plane_at(zp, j1 >> 1); zc = plane_at(zp, j2 >> 1); }
+                } else { za = plane_at(zp_q, j0 >> 1); zb = plane_at(zp_q, j1 >> 1); zc = plane_at(zp_q, j2 >> 1); }
                 int x0, y0, npx, npy;
                 sample_box<S>(min(a0.x, min(a1.x, a2.x)), max(a0.x, max(a1.x, a2.x)), min(a0.y, min(a1.y, a2.y)), max(a0.y, max(a1.y, a2.y)), g, x0, y0, npx, npy);
                 const int32_t A = -(mul_small(a1.x - a0.x, a2.y - a0.y) - mul_small(a2.x - a0.x, a1.y - a0.y));
-                drawn = micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_view, g);
+                drawn = micro_draw<S>(micro_edges(a0, a1, a2), x0, y0, npx, npy, za, zb, zc, 1.0f / (float)A, t, vis_q, g);
                 // every block the box reaches into may hold something now.  One block as a rule; a box of up to micro_pixels
                 // pixels can be a sliver one pixel wide and 32 rows tall (five rows of blocks) or the transpose (two columns).
                 static_assert(micro_pixels<S>() <= (int)kFlagBlockW, "a micro-triangle's box spans two block columns at most");
@@ -642,10 +662,14 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
             }
             if (drawn)
                 for (uint32_t by = by0; by <= by1; ++by) {
-                    flags.at(view0 + view, bx0, by) = 1u;
-                    if (bx1 != bx0) flags.at(view0 + view, bx1, by) = 1u;
+                    flags.at(view0 + qv, bx0, by) = 1u;
+                    if (bx1 != bx0) flags.at(view0 + qv, bx1, by) = 1u;
                 }
             n_micro += (uint32_t)__popcll(__ballot(drawn));   // of the wave
+        }
+        if constexpr (VIEW_LOOP) {
+            __syncthreads();        // (the entries are read: the next view's pushes may take their places)
+            q_total = 0;
         }
     }
     if (n_unproj) atomicAdd(&b.counters[kCtrUnprojectable], n_unproj);   // rare
