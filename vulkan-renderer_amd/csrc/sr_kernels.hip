@@ -2150,7 +2150,10 @@ void launch_vertex(hipStream_t st, const float* px, const float* py, const float
     // dozen streams per workgroup the stores lose more in the memory system than reading the positions once more costs (the
     // 50 M-triangle batch, 34 views per pass: every view per workgroup 11.2 ms, sixteen 11.0 ms, eight 10.0 ms, four 9.9 ms).
     const uint32_t grid_x = div_up(n, kBatchVertexGroup * 256u);
-    uint32_t views_per_block = std::min<uint32_t>({std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views, kVertexViewsPerBlock});
+    // (without a depth plane a view is one output stream, not two: the same batch, 34 views per pass, 8 views per workgroup 6.3 ms, 16 -- three
+    // rows of 12 -- 5.9 ms, 32 -- two rows of 17 -- 6.3 ms)
+    const uint32_t most_views = out.z ? kVertexViewsPerBlock : 2u * kVertexViewsPerBlock;
+    uint32_t views_per_block = std::min<uint32_t>({std::max<uint32_t>((uint32_t)((uint64_t)n_views * grid_x / std::max(fill_blocks, 1u)), 1u), n_views, most_views});
     views_per_block = div_up(n_views, div_up(n_views, views_per_block));   // the same number of rows of workgroups, evenly filled (17 views: 6 + 6 + 5, not 8 + 8 + 1)
     if (grid_x < std::max(fill_blocks, 1u)) {   // a small mesh: one launch, a row of workgroups per group of views
         vertex_kernel<<<dim3(grid_x, div_up(n_views, views_per_block)), 256, 0, st>>>(px, py, pz, n, views, n_views, views_per_block, W, H, out, debug_out,
