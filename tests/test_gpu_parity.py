@@ -805,8 +805,8 @@ def test_lean_view_batches_store_no_depth_plane(sr, oracle, samples):
             stats = {name: tgt[name].stats() for name in devices}
             assert stats["default"]["triangles_binned"] == 0 and stats["default"]["triangles_clipped"] == 0      # nothing pending: the repeats are lean
             assert stats["passes"]["passes"] > 1
-            for name in ("looping", "stored"):
-                assert stats[name] == stats["default"], (k, name)
+            for name in ("looping", "stored"):       # (passes: a pass without the depth plane holds more views)
+                assert {x: y for x, y in stats[name].items() if x != "passes"} == {x: y for x, y in stats["default"].items() if x != "passes"}, (k, name)
         for name, d in devices.items():
             c = d.draw_counts()
             assert c["lean_draws"] == 2 and c["lean_redraws"] == 0, (name, c)
