@@ -1843,24 +1843,62 @@ __device__ __forceinline__ void fragment_body(const FragParams& p)
         s_lvl[tid] = m == 0 ? p.albedo.level_off[l] : m == 1 ? p.metallic.level_off[l] : m == 2 ? p.roughness.level_off[l] : p.normal.level_off[l];
     }
     __syncthreads();
-    if (!inside) return;
-    const int x = p.g.rx + lx, y = p.g.ry + ly;
     const ViewXform& vx = p.views[view];
     uint32_t col[S];
+    if constexpr (S == 1) {
+        if (!inside) return;
+        col[0] = ids[0] == kNoTri ? kColorClear : shade_pixel<ANISO, IDENT, NMAP>(p, vx, ids[0], p.g.rx + lx, p.g.ry + ly, s_dec, s_thr, s_lvl);
+    } else {
+        // Several samples per pixel: a pixel is shaded once per DISTINCT triangle among its samples.  Done pixel by pixel, a wave takes
+        // as many turns through the shading code as its worst pixel has triangles (four, wherever a vertex lies inside a pixel), most
+        // lanes idle in the later ones.  So the workgroup first lists its (pixel, triangle) pairs in LDS, shades the list with every
+        // lane busy -- kFragTurns turns of 256 pairs at most, as many as the list needs -- and every pixel then picks up the colours
+        // of its samples' triangles.
+        constexpr uint32_t kFragTurns = S;
+        __shared__ uint32_t s_pair_tri[kFragTurns * 256u], s_pair_px[kFragTurns * 256u], s_pair_col[kFragTurns * 256u];
+        __shared__ uint32_t s_wave_pairs[4];
+        uint32_t uniq[S];
+        int slot_of[S];     // which of the pixel's distinct triangles covers sample s; -1: none
+        uint32_t n = 0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (ids[s] == kNoTri) { col[s] = kColorClear; continue; }
-        int prev = -1;
+        for (int s = 0; s < S; ++s) {
+            slot_of[s] = -1;
+            if (ids[s] == kNoTri) continue;
 #pragma unroll
-        for (int k = 0; k < s; ++k) if (prev < 0 && ids[k] == ids[s]) prev = k;
-        if (prev >= 0) {
-            uint32_t c = 0;
+            for (int k = 0; k < s; ++k) if (slot_of[s] < 0 && slot_of[k] >= 0 && ids[k] == ids[s]) slot_of[s] = slot_of[k];
+            if (slot_of[s] < 0) {
 #pragma unroll
-            for (int k = 0; k < s; ++k) if (k == prev) c = col[k];
-            col[s] = c;
-        } else {
-            col[s] = shade_pixel<ANISO, IDENT, NMAP>(p, vx, ids[s], x, y, s_dec, s_thr, s_lvl);
+                for (int k = 0; k < S; ++k) if ((uint32_t)k == n) uniq[k] = ids[s];     // (no indexing of registers by a variable)
+                slot_of[s] = (int)n++;
+            }
         }
+        const uint32_t lane = lane_id(), wave = tid >> 6;
+        uint32_t incl = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += v; }
+        if (lane == 63u) s_wave_pairs[wave] = incl;
+        __syncthreads();
+        uint32_t first = incl - n, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) { if (w < wave) first += s_wave_pairs[w]; total += s_wave_pairs[w]; }
+#pragma unroll
+        for (int k = 0; k < S; ++k)
+            if ((uint32_t)k < n) { s_pair_tri[first + k] = uniq[k]; s_pair_px[first + k] = tid | ((uint32_t)k << 8); }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t turn = 0; turn < kFragTurns; ++turn) {
+            const uint32_t w = turn * 256u + tid;
+            if (w < total) {
+                const uint32_t px = s_pair_px[w], t = px & 255u;
+                // (the pixel of work-item t of this workgroup: the launch is kFragBlockW wide)
+                const int wx = p.g.rx + (int)(blockIdx.x * kFlagBlockW + (t % kFlagBlockW)), wy = p.g.ry + (int)(blockIdx.y * kFlagBlockH + (t / kFlagBlockW));
+                s_pair_col[(px >> 8) * 256u + t] = shade_pixel<ANISO, IDENT, NMAP>(p, vx, s_pair_tri[w], wx, wy, s_dec, s_thr, s_lvl);
+            }
+        }
+        __syncthreads();
+        if (!inside) return;
+#pragma unroll
+        for (int s = 0; s < S; ++s) col[s] = slot_of[s] < 0 ? kColorClear : s_pair_col[(uint32_t)slot_of[s] * 256u + tid];
     }
     uint32_t outc;
     if (S == 1) outc = col[0];
