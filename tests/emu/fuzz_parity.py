@@ -7,6 +7,9 @@ the percentage to mean something).
     python tests/emu/fuzz_parity.py [first_seed [count]]        SR_FUZZ_ANISOTROPIC=1: samplers with maxAnisotropy 16 on both sides
                                                                 SR_FUZZ_GPU=1: the shipped library on GPU 0 instead of the CPU execution
                                                                 of the kernel sources (same cases, same checks; a GPU box only)
+                                                                SR_FUZZ_MANY_VIEWS=1: 9 to 14 views per case instead of 1 to 3 (with SR_FILL_BLOCKS=1 the
+                                                                workgroups of the vertex and set-up kernels loop over them; with SR_TEST_DRAWS=2 the scenes of
+                                                                small triangles are lean on the second draw and store no depth plane)
 """
 import os
 import sys
@@ -65,6 +68,8 @@ def scene_of_seed(seed, sr):
         W, H = int(rng.integers(600, 1500)), int(rng.integers(400, 900))
     samples = int(rng.choice([1, 4]))
     n_views = int(rng.integers(1, 4))
+    if os.environ.get("SR_FUZZ_MANY_VIEWS") == "1":   # batches of more views than travel as kernel arguments (the same scenes otherwise: the draw follows the others)
+        n_views = int(np.random.default_rng(seed + 7919).integers(9, 15))
     rect = None
     if rng.integers(0, 3) == 0:
         x, y = int(rng.integers(0, W)), int(rng.integers(0, H))

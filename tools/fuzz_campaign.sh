@@ -11,3 +11,5 @@ SR_FUZZ_GPU=1 SR_TEST_DRAWS=2 SR_STAGED_MIN_BLOCKS=1 SR_CULL_MIN_CHUNKS=1 timeou
 tail -1 $out/two_draws_staged_culled.log
 SR_FUZZ_GPU=1 SR_FUZZ_ANISOTROPIC=1 SR_TEST_DRAWS=2 timeout -k 10 900 python -u tests/emu/fuzz_parity.py $((f + 2 * n)) $n > $out/anisotropic_two_draws.log 2>&1 || { tail -5 $out/anisotropic_two_draws.log; exit 1; }
 tail -1 $out/anisotropic_two_draws.log
+SR_FUZZ_GPU=1 SR_FUZZ_MANY_VIEWS=1 SR_FILL_BLOCKS=1 SR_TEST_DRAWS=2 timeout -k 10 900 python -u tests/emu/fuzz_parity.py $((f + 3 * n)) $((n / 4)) > $out/many_views_looping_two_draws.log 2>&1 || { tail -5 $out/many_views_looping_two_draws.log; exit 1; }
+tail -1 $out/many_views_looping_two_draws.log
