@@ -174,12 +174,17 @@ def test_differential_fuzzing_against_the_oracle():
     scene, with trilinear and with 16x anisotropic samplers."""
     build_emulation_library()
     script = os.path.join(ROOT, "tests", "emu", "fuzz_parity.py")
-    runs = [(a, first, subprocess.Popen([sys.executable, script, str(first), "24"], env=dict(os.environ, SR_FUZZ_ANISOTROPIC=a), stdout=subprocess.PIPE,
-                                        stderr=subprocess.STDOUT, text=True))
-            for a, first in (("0", 0), ("0", 100), ("0", 2300), ("1", 300), ("0", 3400), ("1", 3500))]
-    for a, first, proc in runs:
+    # the last two: every frame drawn twice (the second draw takes the lean and direct paths); batches of 9 to 14 views whose vertex and
+    # set-up workgroups loop over the views, drawn twice (lean repeats store no depth plane)
+    many = dict(SR_FUZZ_MANY_VIEWS="1", SR_FILL_BLOCKS="1", SR_TEST_DRAWS="2")
+    kinds = ((dict(SR_FUZZ_ANISOTROPIC="0"), 0, 24), (dict(SR_FUZZ_ANISOTROPIC="0"), 100, 24), (dict(SR_FUZZ_ANISOTROPIC="0"), 2300, 24), (dict(SR_FUZZ_ANISOTROPIC="1"), 300, 24),
+             (dict(SR_FUZZ_ANISOTROPIC="0"), 3400, 24), (dict(SR_FUZZ_ANISOTROPIC="1"), 3500, 24), (dict(SR_TEST_DRAWS="2", SR_STAGED_MIN_BLOCKS="1", SR_CULL_MIN_CHUNKS="1"), 5000, 24),
+             (many, 7000, 10))
+    runs = [(env, first, subprocess.Popen([sys.executable, script, str(first), str(count)], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+            for env, first, count in kinds]
+    for env, first, proc in runs:
         out, _ = proc.communicate(timeout=1500)
-        assert proc.returncode == 0 and "ok: seeds" in out, f"anisotropic {a}, first seed {first}:\n{out[-3000:]}"
+        assert proc.returncode == 0 and "ok: seeds" in out, f"{env}, first seed {first}:\n{out[-3000:]}"
 
 
 def test_benchmark_and_smoke_scripts_run_end_to_end():
