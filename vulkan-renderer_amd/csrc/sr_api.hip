@@ -98,6 +98,11 @@ struct sr_device_t {
     uint32_t cull_min_chunks = 8;                  // meshes of fewer chunks are not worth the extra launch (SR_CULL_MIN_CHUNKS)
     bool cull_enabled = true;                      // SR_NO_CULL=1 turns it off
     bool recompute_depth = true;                    // lean draws of view batches store no depth plane (SR_STORE_DEPTH=1: always store it)
+    // Pairs of maps of the same size whose red channels have been packed into one chain for the shading pass (the reference's metallic and
+    // roughness maps: eight texel loads per pixel instead of sixteen).  Made by the first sr_draw that uses the pair; gone with either map.
+    struct PackedPair { const sr_texture_t* a; const sr_texture_t* b; uint32_t* d_chain; };
+    std::vector<PackedPair> packed_pairs;
+    bool pack_pairs = true;                         // (SR_NO_PACKED_MAPS=1: never)
     uint32_t direct_max_triangles = 500000;         // pending triangles of a draw (all its views) up to which it skips the tile path (SR_DIRECT_MAX_TRIANGLES; 0: never)
 };
 
@@ -191,6 +196,21 @@ CullView make_cull_view(const ViewXform& x)
     }
     v.scale = (float)scale;
     return v;
+}
+
+// the chain that holds the red channels of a and b (same size), made now unless the caller may not allocate; null if there is none
+const uint32_t* packed_pair(sr_device_t* dev, const sr_texture_t* a, const sr_texture_t* b, bool may_allocate)
+{
+    if (!dev->pack_pairs || !a || !b || a->w != b->w || a->h != b->h || a->levels != b->levels || a->total_texels != b->total_texels ||
+        std::memcmp(a->level_off, b->level_off, sizeof a->level_off) != 0)
+        return nullptr;
+    for (const auto& p : dev->packed_pairs) if (p.a == a && p.b == b) return p.d_chain;
+    if (!may_allocate) return nullptr;
+    uint32_t* chain = nullptr;
+    if (hipMalloc((void**)&chain, std::max<size_t>(a->total_texels, 1) * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    launch_pack_red_channels(dev->stream, a->d_chain, b->d_chain, a->total_texels, chain);
+    dev->packed_pairs.push_back({a, b, chain});
+    return chain;
 }
 
 TexDesc make_tex_desc(const sr_texture_t* t)
@@ -435,6 +455,7 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (f.normal_mapping) f.normal = make_tex_desc(tg->tex[1]);
         f.decode = dev->d_decode; f.thresh = dev->d_thresh; f.view0 = v0; f.n_views = nv; f.flags = tg->flags;
         f.report = PassReport{b.counters, b.pending_total, nv, b.micro_spread, tg->lean ? pass_counters : nullptr};
+        f.packed_mr = packed_pair(dev, metallic, roughness, !no_alloc);
         f.identity_model = true;
         for (uint32_t v = v0; v < v0 + nv; ++v) f.identity_model = f.identity_model && tg->views[v].model_is_identity != 0.0f;
         launch_fragment(st, f);
@@ -563,6 +584,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* v = std::getenv("SR_CULL_MIN_CHUNKS")) dev->cull_min_chunks = (uint32_t)std::max(1, std::atoi(v));   // tests: cull small meshes too
     if (std::getenv("SR_NO_CULL")) dev->cull_enabled = false;
     if (const char* v = std::getenv("SR_STORE_DEPTH")) dev->recompute_depth = std::atoi(v) == 0;
+    if (const char* v = std::getenv("SR_NO_PACKED_MAPS")) dev->pack_pairs = std::atoi(v) == 0;
     if (const char* v = std::getenv("SR_DIRECT_MAX_TRIANGLES")) dev->direct_max_triangles = (uint32_t)std::max(0, std::atoi(v));
     if (const char* v = std::getenv("SR_STAGED_MIN_BLOCKS")) dev->staged_min_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = the staged resolve for small launches too
     if (const char* v = std::getenv("SR_SCRATCH_MIB")) dev->scratch_budget = (size_t)std::max(1, std::atoi(v)) << 20;   // small budgets: many passes per draw
@@ -580,6 +602,7 @@ int sr_device_destroy(sr_device dev)
     dev->pending.release(); dev->refs.release(); dev->views.release(); dev->clip.release();
     dev->cull_visible.release(); dev->cull_stamp.release(); (void)hipFree(dev->d_cull_counts);
     for (auto& sg : dev->staging) { if (sg.h) (void)hipHostFree(sg.h); if (sg.ev) (void)hipEventDestroy(sg.ev); }
+    for (auto& p : dev->packed_pairs) (void)hipFree(p.d_chain);
     (void)hipFree(dev->d_decode); (void)hipFree(dev->d_thresh);
     if (dev->stream) (void)hipStreamDestroy(dev->stream);
     for (sr_target_t* t : dev->targets) { t->mesh = nullptr; t->check_pending = false; }   // targets outliving their device can only be destroyed
@@ -694,6 +717,11 @@ int sr_texture_destroy(sr_device dev, sr_texture tex)
         (void)hipSetDevice(dev->ordinal);
         release_references(dev, nullptr, tex);
         (void)hipStreamSynchronize(dev->stream);
+        for (size_t k = dev->packed_pairs.size(); k-- > 0;)        // the chains that pack this map with another
+            if (dev->packed_pairs[k].a == tex || dev->packed_pairs[k].b == tex) {
+                (void)hipFree(dev->packed_pairs[k].d_chain);
+                dev->packed_pairs.erase(dev->packed_pairs.begin() + (long)k);
+            }
     }
     (void)hipFree(tex->d_chain);
     delete tex;

@@ -1624,7 +1624,8 @@ struct FragParams {
     TexDesc normal;            // read only by the kernels compiled with normal mapping
     ShadeTables tab;
     uint32_t view0;            // first view of this pass inside the target
-    uint32_t paired;           // 1: the metallic and roughness maps have the same size and sampler state, so one set of footprints serves both
+    const uint32_t* packed_mr; // the metallic and roughness maps have the same size and sampler state and the device holds their red channels packed into
+                               // one chain (launch_pack_red_channels): one set of footprints and one set of texel loads serves both.  Null: two fetches
     uint32_t lod_shared;       // bit 0 / 1: the metallic / roughness map has the albedo map's proportions (w_m * h_a == h_m * w_a), so its
     float lod_shift[2];        // log2(rho) is the albedo map's + lod_shift = log2(w_m / w_a)
     BlockFlags flags;          // written here, read by the start of the next draw
@@ -1772,9 +1773,12 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
         fetch_trilinear<3>(p.albedo.texels, trilinear_taps_at(p.albedo, lvl, u, v, la), dec, alb);
         const float lm = p.lod_shared & 1u ? la + p.lod_shift[0] : lod_of_footprint(p.metallic, dudx, dvdx, dudy, dvdy);   // (the same choice for the whole launch)
         const TrilinearTaps tm = trilinear_taps_at(p.metallic, lvl + kMaxMipLevels, u, v, lm);
-        fetch_trilinear<1>(p.metallic.texels, tm, dec, met);
-        if (p.paired) fetch_trilinear<1>(p.roughness.texels, tm, dec, rgh);    // the same for the whole launch
-        else {
+        if (p.packed_mr) {     // (the same for the whole launch) one map holds both: a texel's red byte is the metallic map's, its green byte the roughness map's
+            float mr[2];
+            fetch_trilinear<2>(p.packed_mr, tm, dec, mr);
+            met[0] = mr[0]; rgh[0] = mr[1];
+        } else {
+            fetch_trilinear<1>(p.metallic.texels, tm, dec, met);
             const float lr = p.lod_shared & 2u ? la + p.lod_shift[1] : lod_of_footprint(p.roughness, dudx, dvdx, dudy, dvdy);
             fetch_trilinear<1>(p.roughness.texels, trilinear_taps_at(p.roughness, lvl + 2 * kMaxMipLevels, u, v, lr), dec, rgh);
         }
@@ -1937,6 +1941,13 @@ __global__ __launch_bounds__(256) SR_FRAG_ATTR void fragment_report_kernel(FragP
 // mip-chain builder: one linear blit per level (src/texture.cpp:119-164), sRGB-correct
 // =================================================================================================
 // a workgroup of kMipBlockW * kMipBlockH work-items (one-dimensional) covers kMipBlockW x kMipBlockH texels of the destination
+// Two maps of the same size of which the shader reads the red channel only (the reference's metallic and roughness maps): texel i of
+// the result holds a's red byte and, above it, b's.
+__global__ __launch_bounds__(256) void pack_red_channels_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, uint32_t* __restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) out[i] = (a[i] & 255u) | ((b[i] & 255u) << 8);
+}
+
 constexpr uint32_t kMipBlockW = 32, kMipBlockH = 8;
 __global__ __launch_bounds__(256) void mip_blit_kernel(const uint32_t* __restrict__ src, int sw, int sh, uint32_t* __restrict__ dst, int dw, int dh,
                                                        ShadeTables tab)
@@ -2326,8 +2337,9 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
     p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness; p.normal = f.normal;
     p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.flags = f.flags; p.report = f.report;
     const TexDesc &m = f.metallic, &r = f.roughness;
-    p.paired = m.w == r.w && m.h == r.h && m.levels == r.levels && m.min_lod == r.min_lod && m.max_lod == r.max_lod && m.bias == r.bias &&
-               std::memcmp(m.level_off, r.level_off, sizeof m.level_off) == 0;
+    const bool same_sampling = m.w == r.w && m.h == r.h && m.levels == r.levels && m.min_lod == r.min_lod && m.max_lod == r.max_lod && m.bias == r.bias &&
+                               std::memcmp(m.level_off, r.level_off, sizeof m.level_off) == 0;
+    p.packed_mr = same_sampling ? f.packed_mr : nullptr;
     p.lod_shared = 0u; p.lod_shift[0] = p.lod_shift[1] = 0.0f;
     const TexDesc* other[2] = {&f.metallic, &f.roughness};
     for (int k = 0; k < 2; ++k)
@@ -2360,6 +2372,11 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
         else SR_LAUNCH_FRAGMENT(4, false, false);
     }
 #undef SR_LAUNCH_FRAGMENT
+}
+
+void launch_pack_red_channels(hipStream_t st, const uint32_t* a, const uint32_t* b, size_t n_texels, uint32_t* out)
+{
+    if (n_texels) pack_red_channels_kernel<<<(uint32_t)std::min<size_t>((n_texels + 255) / 256, 1u << 20), 256, 0, st>>>(a, b, n_texels, out);
 }
 
 void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh)

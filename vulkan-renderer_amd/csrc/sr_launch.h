@@ -21,6 +21,7 @@ struct FragLaunch {
     BlockFlags flags;          // of the target
     PassReport report;         // host_counters != null: the shading pass reports the counters of the pass (lean draws)
     bool identity_model;       // the model matrix of every one of these views is the identity
+    const uint32_t* packed_mr; // launch_pack_red_channels of the metallic and the roughness chain (used when their sampling is the same too), or null
 };
 
 constexpr uint32_t kMaxPackedViews = 8;   // views whose transforms fit the kernel arguments of launch_store_views
@@ -72,6 +73,8 @@ uint32_t setup_block_triangles();   // triangles handled by one set-up block
 uint32_t chunk_triangles();         // triangles of one chunk of the pending list (what one turn of a binning workgroup takes)
 uint32_t setup_block_records();     // size of the record segment one chunk owns
 void launch_fragment(hipStream_t st, const FragLaunch& f);
+// out[i] = red byte of a[i] | red byte of b[i] << 8, for whole mip chains of two maps of the same size
+void launch_pack_red_channels(hipStream_t st, const uint32_t* a, const uint32_t* b, size_t n_texels, uint32_t* out);
 void launch_mip_blit(hipStream_t st, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, const float* decode, const float* thresh);
 void launch_split_vis(hipStream_t st, const uint64_t* vis, size_t n, float* depth, uint32_t* tri);
 void launch_stats(hipStream_t st, const uint64_t* vis, size_t n_pixels, int S, uint32_t* tri_flag, uint32_t n_tris, uint64_t* shaded, uint64_t* visible);
