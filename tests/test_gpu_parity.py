@@ -815,6 +815,52 @@ def test_lean_view_batches_store_no_depth_plane(sr, oracle, samples):
             d.close()
 
 
+@pytest.mark.parametrize("samples", [1, 4])
+def test_metallic_and_roughness_maps_packed_into_one_chain(sr, oracle, samples):
+    """The first draw that uses a metallic and a roughness map of the same size packs their red channels into one chain, and the shading
+    pass fetches both with one set of loads.  The frame is the one a device without packing draws, bit for bit, and the oracle's: maps
+    with different content in every channel, non-power-of-two maps, one map used for both, and -- after one of the pair has been
+    destroyed and another map created in its place -- the new pair."""
+    W, H = 320, 200
+    verts, idx = sr.scene.uv_sphere(48, 36)
+    ubo = sr.scene.default_camera_ubo(W, H)
+    rng = np.random.default_rng(11)
+    def noise(w, h):
+        return rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    sets = [[noise(64, 64), noise(8, 8), noise(32, 32), noise(32, 32)], [noise(50, 20), noise(8, 8), noise(33, 7), noise(33, 7)]]
+    packing, plain = util.device_with_env(sr), util.device_with_env(sr, SR_NO_PACKED_MAPS="1")
+    try:
+        for images in sets:
+            got = {}
+            for d in (packing, plain):
+                got[d] = util.gpu_render(sr, d, verts, idx, images, ubo, W, H, samples)[0]
+            _check_view(got[packing], oracle.draw(ubo, verts, idx, images, W, H, samples, threads=4))
+            assert np.array_equal(got[packing]["bgra"], got[plain]["bgra"]) and np.array_equal(got[packing]["vis"], got[plain]["vis"])
+        # one map for both; then the roughness map destroyed and replaced (the packed chain of the old pair must not be used for the new one)
+        images = sets[0]
+        mesh = sr.create_mesh_from_data(packing, verts, idx)
+        tex = [sr.create_texture(packing, im) for im in images]
+        tgt = sr.RenderTarget(packing, W, H, samples=samples)
+        both = [tex[0], tex[1], tex[2], tex[2]]
+        sr.draw(packing, tgt, mesh, ubo, both)
+        _check_view({"tri": tgt.read_triangle_ids(0), "depth": tgt.read_depth(0), "bgra": tgt.read_color(0)},
+                    oracle.draw(ubo, verts, idx, [images[0], images[1], images[2], images[2]], W, H, samples, threads=4))
+        sr.draw(packing, tgt, mesh, ubo, tex)
+        first = tgt.read_color(0)
+        tex[3].destroy()
+        other = noise(32, 32)
+        tex[3] = sr.create_texture(packing, other)
+        sr.draw(packing, tgt, mesh, ubo, tex)
+        second = {"tri": tgt.read_triangle_ids(0), "depth": tgt.read_depth(0), "bgra": tgt.read_color(0)}
+        _check_view(second, oracle.draw(ubo, verts, idx, [images[0], images[1], images[2], other], W, H, samples, threads=4))
+        assert (second["bgra"] != first).any()
+        tgt.destroy(); mesh.destroy()
+        for t in tex:
+            t.destroy()
+    finally:
+        packing.close(); plain.close()
+
+
 def test_staged_resolve_gives_the_same_frames(sr, oracle, device):
     """A one-sample, one-view set-up launch of thousands of workgroups resolves its micro-triangles' samples through LDS (marked per lane,
     numbered per wave, resolved by whole waves); smaller launches resolve inside each lane's walk.  Forced on for small launches
