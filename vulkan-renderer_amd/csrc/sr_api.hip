@@ -112,7 +112,7 @@ struct sr_mesh_t {
     uint32_t* d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
     float4* d_chunk_sphere = nullptr;   // chunk culling: bounds of every chunk of setup_block_triangles() triangles ([chunks] spheres, then
-    uint2* d_chunk_vrange = nullptr;    // [chunks] vertex ranges in the same allocation)
+    uint4* d_chunk_vrange = nullptr;    // [chunks] vertex ranges in the same allocation)
     uint32_t n_chunks = 0;
 };
 
@@ -649,9 +649,9 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
     if (e == hipSuccess) launch_split_positions(dev->stream, m->d_aos, n_vertices, m->px, m->py, m->pz);
     if (e == hipSuccess && n_tris) {   // bounds of every chunk, for draws into a restricted rectangle
         m->n_chunks = (n_tris + setup_block_triangles() - 1) / setup_block_triangles();
-        e = hipMalloc((void**)&m->d_chunk_sphere, (size_t)m->n_chunks * (sizeof(float4) + sizeof(uint2)));
+        e = hipMalloc((void**)&m->d_chunk_sphere, (size_t)m->n_chunks * (sizeof(float4) + sizeof(uint4)));
         if (e == hipSuccess) {
-            m->d_chunk_vrange = (uint2*)(m->d_chunk_sphere + m->n_chunks);
+            m->d_chunk_vrange = (uint4*)(m->d_chunk_sphere + m->n_chunks);
             launch_chunk_bounds(dev->stream, m->d_idx, n_tris, m->d_aos, m->d_chunk_sphere, m->d_chunk_vrange);
         }
     }

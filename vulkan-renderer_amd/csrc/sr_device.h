@@ -238,7 +238,8 @@ struct CullView {            // rows x, y, w of (proj * view * model), their 3-v
 };
 struct ChunkCull {
     const float4* sphere;    // [chunks]: centre, radius (infinite when a position is not finite)
-    const uint2* vrange;     // [chunks]: lowest and highest vertex number the chunk's triangles use
+    const uint4* vrange;     // [chunks]: lowest and highest vertex number the chunk's triangles use; z, w: bit k set = the chunk uses a vertex of
+                             // group (lowest / kCullVertexGroup + k), k < 64
     uint32_t n_chunks;
     uint32_t* visible;       // [chunks], written per draw: 0 = the chunk cannot touch the stored rectangle
     uint32_t* stamp;         // [1 + vertex groups]: == epoch when the group (word 0: every group) must be transformed in this draw

@@ -1995,12 +1995,13 @@ __device__ inline float block_reduce(float v, bool take_max, float* s_tmp /* 4 f
 // One workgroup per chunk: bounding sphere (centre of the bounding box, largest distance of a referenced position from it, a few ulp
 // added) and the range of vertex numbers.  A position that is not finite makes the radius infinite: such a chunk is never culled.
 __global__ __launch_bounds__(256) void chunk_bounds_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, const float4* __restrict__ verts /* 2 float4 per vertex */,
-                                                           float4* __restrict__ sphere, uint2* __restrict__ vrange)
+                                                           float4* __restrict__ sphere, uint4* __restrict__ vrange)
 {
     __shared__ float s_tmp[4];
-    __shared__ uint32_t s_lo, s_hi;
+    __shared__ uint32_t s_lo, s_hi, s_groups[2];
     const uint32_t tid = threadIdx.x, first = blockIdx.x * kChunkCullTris;
-    if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
+    if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; s_groups[0] = s_groups[1] = 0u; }
+    uint32_t vid[3 * kSetupTris];
     float p[3 * kSetupTris][3];
     bool have[kSetupTris];
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -2013,6 +2014,7 @@ __global__ __launch_bounds__(256) void chunk_bounds_kernel(const uint32_t* __res
 #pragma unroll
         for (uint32_t c = 0; c < 3u; ++c) {
             const uint32_t i = have[k] ? idx[3 * (size_t)t + c] : 0u;
+            vid[3 * k + c] = i;
             const float4 a = have[k] ? verts[2 * (size_t)i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             p[3 * k + c][0] = a.x; p[3 * k + c][1] = a.y; p[3 * k + c][2] = a.z;
             if (have[k]) {
@@ -2042,11 +2044,23 @@ __global__ __launch_bounds__(256) void chunk_bounds_kernel(const uint32_t* __res
     const float all_finite = block_reduce(finite ? 1.0f : 0.0f, false, s_tmp, tid);
     atomicMin(&s_lo, vlo); atomicMax(&s_hi, vhi);
     __syncthreads();
+    // which of the groups of kCullVertexGroup vertices from the lowest one's on the chunk's triangles use (the first 64 of them: a chunk
+    // that spans more has every vertex transformed anyway)
+    const uint32_t group0 = s_lo / kCullVertexGroup;
+#pragma unroll
+    for (uint32_t k = 0; k < kSetupTris; ++k)
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c)
+            if (have[k]) {
+                const uint32_t gi = vid[3 * k + c] / kCullVertexGroup - group0;
+                if (gi < 64u) atomicOr(&s_groups[gi >> 5], 1u << (gi & 31u));
+            }
+    __syncthreads();
     if (tid == 0) {
         float r = sqrtf(r2) * 1.00001f + 1.0e-30f;            // (rounding of the squares and the root: a few ulp; this adds a thousand)
         if (!(all_finite > 0.5f) || !(r <= 3.0e38f)) r = __builtin_inff();
         sphere[blockIdx.x] = make_float4(centre[0], centre[1], centre[2], r);
-        vrange[blockIdx.x] = make_uint2(s_lo, s_hi);
+        vrange[blockIdx.x] = make_uint4(s_lo, s_hi, s_groups[0], s_groups[1]);
     }
 }
 
@@ -2080,11 +2094,12 @@ __global__ __launch_bounds__(256) void chunk_cull_kernel(ChunkCull cc, CullView 
         }
         cc.visible[chunk] = culled ? 0u : 1u;
         if (!culled) {
-            const uint2 r = cc.vrange[chunk];
+            const uint4 r = cc.vrange[chunk];
             const uint32_t g0 = r.x / kCullVertexGroup, g1 = r.y / kCullVertexGroup;
+            const uint64_t used = (uint64_t)r.z | ((uint64_t)r.w << 32);
             if (r.x > r.y) { /* a chunk without triangles refers to no vertex */ }
             else if (g1 - g0 >= kCullMaxGroupsPerChunk) cc.stamp[0] = cc.epoch;      // scattered indices: every group (same value from every writer)
-            else for (uint32_t k = g0; k <= g1; ++k) cc.stamp[1u + k] = cc.epoch;
+            else for (uint32_t k = g0; k <= g1; ++k) if ((used >> (k - g0)) & 1ull) cc.stamp[1u + k] = cc.epoch;    // (a strip of a grid mesh: two short runs of vertices a row apart)
         }
     }
     const uint64_t m = __ballot(culled), all = __ballot(chunk < cc.n_chunks);
@@ -2308,7 +2323,7 @@ void launch_raster(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const S
     else if (g.samples == 4 && g.tile_log2 == 4) raster_kernel<4, 4, 256><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b.tile_offset, b.refs, b.ref_capacity, v, flags, view0);
 }
 
-void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint2* vrange)
+void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint4* vrange)
 {
     if (!n_tris) return;
     chunk_bounds_kernel<<<div_up(n_tris, kChunkCullTris), 256, 0, st>>>(idx, n_tris, (const float4*)verts_aos, sphere, vrange);

@@ -54,7 +54,7 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
                   uint32_t staged_min_blocks = kStagedResolveMinBlocks,
                   const DepthSource* depth_source = nullptr /* set: sp.z is null, set-up works depths out itself; set-up only, no binning */);
 // chunk culling (sr_device.h): bounds of every chunk of setup_block_triangles() triangles, once per mesh; the per-draw test
-void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint2* vrange);
+void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint4* vrange);
 void launch_chunk_cull(hipStream_t st, const ChunkCull& cc, const CullView& v, const FrameGeom& g);
 // near-plane clipping of the triangles set-up listed: cuts them and resolves the pieces into the visibility buffer.
 // Runs after launch_setup and before launch_scan (which reports the counters to the host).
