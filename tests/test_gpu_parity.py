@@ -816,7 +816,7 @@ def test_lean_view_batches_store_no_depth_plane(sr, oracle, samples):
 
 
 @pytest.mark.parametrize("samples", [1, 4])
-def test_metallic_and_roughness_maps_packed_into_one_chain(sr, oracle, samples):
+def test_metallic_and_roughness_maps_packed_into_one_chain(sr, oracle, samples, anisotropic):
     """The first draw that uses a metallic and a roughness map of the same size packs their red channels into one chain, and the shading
     pass fetches both with one set of loads.  The frame is the one a device without packing draws, bit for bit, and the oracle's: maps
     with different content in every channel, non-power-of-two maps, one map used for both, and -- after one of the pair has been

@@ -1764,8 +1764,16 @@ __device__ inline uint32_t shade_pixel(const FragParams& p, const ViewXform& vx,
     float alb[3], met[1], rgh[1], rgb[3];
     if constexpr (ANISO) {
         sample_texture_aniso<3>(p.albedo, lvl, u, v, dudx, dvdx, dudy, dvdy, dec, alb);
-        sample_texture_aniso<1>(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, met);
-        sample_texture_aniso<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+        if (p.packed_mr) {     // (the same for the whole launch) both maps from the chain that packs them: one set of footprints and loads
+            TexDesc both = p.metallic;
+            both.texels = p.packed_mr;
+            float mr[2];
+            sample_texture_aniso<2>(both, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, mr);
+            met[0] = mr[0]; rgh[0] = mr[1];
+        } else {
+            sample_texture_aniso<1>(p.metallic, lvl + kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, met);
+            sample_texture_aniso<1>(p.roughness, lvl + 2 * kMaxMipLevels, u, v, dudx, dvdx, dudy, dvdy, dec, rgh);
+        }
     } else {
         // A map with the albedo map's proportions scales its footprint by a constant: its log2(rho) is the albedo map's plus the
         // logarithm of the ratio of the widths (FragParams::lod_shift) -- one logarithm per pixel instead of three.
@@ -2352,7 +2360,7 @@ void launch_fragment(hipStream_t st, const FragLaunch& f)
     p.g = f.g; p.albedo = f.albedo; p.metallic = f.metallic; p.roughness = f.roughness; p.normal = f.normal;
     p.tab.decode = f.decode; p.tab.thresh = f.thresh; p.view0 = f.view0; p.flags = f.flags; p.report = f.report;
     const TexDesc &m = f.metallic, &r = f.roughness;
-    const bool same_sampling = m.w == r.w && m.h == r.h && m.levels == r.levels && m.min_lod == r.min_lod && m.max_lod == r.max_lod && m.bias == r.bias &&
+    const bool same_sampling = m.w == r.w && m.h == r.h && m.levels == r.levels && m.min_lod == r.min_lod && m.max_lod == r.max_lod && m.bias == r.bias && m.max_aniso == r.max_aniso &&
                                std::memcmp(m.level_off, r.level_off, sizeof m.level_off) == 0;
     p.packed_mr = same_sampling ? f.packed_mr : nullptr;
     p.lod_shared = 0u; p.lod_shift[0] = p.lod_shift[1] = 0.0f;
