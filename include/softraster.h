@@ -93,6 +93,10 @@ typedef struct sr_draw_counts {
     uint64_t chunks_tested;       /* one-view draws into a target restricted to a rectangle test every chunk of 768 consecutive triangles */
     uint64_t chunks_culled;       /* against the rectangle: chunks (and the vertices only they use) that were skipped because no */
                                   /* triangle of theirs can touch a stored pixel.  The frame is the same with and without. */
+    uint64_t chunk_list_draws;    /* draws of two views or more of a mesh that has chunk vertex lists: set-up workgroups that take several */
+                                  /* views load the distinct vertices of their 768 triangles once per view (about 450 loads instead of */
+                                  /* 2304 on a regular mesh).  A mesh has no lists when a chunk uses more than 1024 distinct vertices or */
+                                  /* vertex numbers 65536 apart.  The frame is the same with and without. */
 } sr_draw_counts;
 
 /* Durations of the last profiled sr_draw, milliseconds, from HIP events on the device's stream. */

@@ -781,7 +781,8 @@ def test_lean_view_batches_store_no_depth_plane(sr, oracle, samples):
     verts[::2, :3] = half
     images = sr.scene.material_textures(32, seed=2)
     devices = {"default": util.device_with_env(sr), "looping": util.device_with_env(sr, SR_FILL_BLOCKS="1"),
-               "passes": util.device_with_env(sr, SR_SCRATCH_MIB="2"), "stored": util.device_with_env(sr, SR_STORE_DEPTH="1")}
+               "passes": util.device_with_env(sr, SR_SCRATCH_MIB="2"), "stored": util.device_with_env(sr, SR_STORE_DEPTH="1"),
+               "looping without lists": util.device_with_env(sr, SR_FILL_BLOCKS="1", SR_NO_CHUNK_VERTS="1")}
     try:
         tex = {k: [sr.create_texture(d, im) for im in images] for k, d in devices.items()}
         mesh = {k: sr.create_mesh_from_data(d, verts, idx) for k, d in devices.items()}
@@ -799,17 +800,76 @@ def test_lean_view_batches_store_no_depth_plane(sr, oracle, samples):
                    for name in devices}
             for v in range(n_views):
                 _check_view(got["default"][v], oracle.draw(u[v], verts, idx, images, W, H, samples, threads=4))
-                for name in ("looping", "passes", "stored"):
+                for name in ("looping", "passes", "stored", "looping without lists"):
                     for key in ("tri", "depth", "bgra"):
                         assert np.array_equal(got[name][v][key], got["default"][v][key]), (k, v, name, key)
             stats = {name: tgt[name].stats() for name in devices}
             assert stats["default"]["triangles_binned"] == 0 and stats["default"]["triangles_clipped"] == 0      # nothing pending: the repeats are lean
             assert stats["passes"]["passes"] > 1
-            for name in ("looping", "stored"):       # (passes: a pass without the depth plane holds more views)
+            for name in ("looping", "stored", "looping without lists"):       # (passes: a pass without the depth plane holds more views)
                 assert {x: y for x, y in stats[name].items() if x != "passes"} == {x: y for x, y in stats["default"].items() if x != "passes"}, (k, name)
         for name, d in devices.items():
             c = d.draw_counts()
             assert c["lean_draws"] == 2 and c["lean_redraws"] == 0, (name, c)
+            assert c["chunk_list_draws"] == (0 if name == "looping without lists" else 3), (name, c)
+    finally:
+        for d in devices.values():
+            d.close()
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_chunk_vertex_lists(sr, oracle, samples):
+    """Set-up workgroups that take several views of a batch load the distinct vertices of their 768 triangles once per view, through
+    lists made when the mesh is created.  Meshes at the limits of the lists: an indexed sphere whose last chunk is a few triangles
+    long; the same triangles in shuffled order with shuffled vertex numbers (chunks of up to 1024 distinct vertices: lists exist only
+    if every chunk fits); vertex numbers spread over more than 65536 (no lists); a triangle soup (2304 distinct vertices per chunk: no
+    lists); chunks whose vertices straddle the span limit by one.  Every view equals the oracle's and the same draw without the lists,
+    bit for bit, on the first (full) and on the repeated (lean) draws, with and without the stored depth plane."""
+    W, H = (160, 90) if samples == 1 else (96, 54)
+    n_views = 9
+    rng = np.random.default_rng(5)
+    verts, idx = sr.scene.uv_sphere(90, 70)
+    tris = idx.reshape(-1, 3)
+    meshes = {"indexed": (verts, idx, True)}
+    renumber = rng.permutation(len(verts)).astype(np.uint32)                 # vertex numbers all over a range of < 65536
+    shuffled_verts = np.empty_like(verts); shuffled_verts[renumber] = verts
+    meshes["renumbered"] = (shuffled_verts, renumber[tris[rng.permutation(len(tris))]].reshape(-1), False)
+    soup_verts = verts[tris.reshape(-1)].copy()
+    meshes["soup"] = (soup_verts, np.arange(len(soup_verts), dtype=np.uint32), False)
+    for gap, fits in ((65535 - int(tris[:768].max()), True), (65536 - int(tris[:768].max()), False)):
+        # the first chunk also uses one vertex `gap` numbers above its highest: a span of exactly 65536 vertex numbers fits, one more does not
+        far = int(tris[:768].max()) + gap
+        wide_verts = np.zeros((max(far + 1, len(verts)), verts.shape[1]), verts.dtype)
+        wide_verts[:len(verts)] = verts
+        wide_verts[far] = verts[int(tris[0, 0])]
+        wide_tris = tris.copy(); wide_tris[0, 0] = far
+        meshes["span %d" % (far - int(wide_tris[:768].min()) + 1)] = (wide_verts, wide_tris.reshape(-1), fits)
+    images = sr.scene.material_textures(16, seed=4)
+    devices = {"lists": util.device_with_env(sr, SR_FILL_BLOCKS="1"), "none": util.device_with_env(sr, SR_FILL_BLOCKS="1", SR_NO_CHUNK_VERTS="1"),
+               "lists, stored depth": util.device_with_env(sr, SR_FILL_BLOCKS="1", SR_STORE_DEPTH="1")}
+    try:
+        tex = {k: [sr.create_texture(d, im) for im in images] for k, d in devices.items()}
+        tgt = {k: sr.RenderTarget(d, W, H, samples=samples, n_views=n_views) for k, d in devices.items()}
+        cams = sr.scene.orbit_ubos(n_views + 1, W, H)
+        for mesh_name, (v_, i_, has_lists) in meshes.items():
+            mesh = {k: sr.create_mesh_from_data(d, v_, i_) for k, d in devices.items()}
+            before = devices["lists"].draw_counts()["chunk_list_draws"]
+            for k in range(2):
+                u = cams[k:k + n_views]
+                for name, d in devices.items():
+                    sr.draw(d, tgt[name], mesh[name], u, tex[name])
+                for v in range(n_views):
+                    got = {name: {"tri": tgt[name].read_triangle_ids(v), "depth": tgt[name].read_depth(v), "bgra": tgt[name].read_color(v)} for name in devices}
+                    if v % 4 == 0:
+                        _check_view(got["lists"], oracle.draw(u[v], v_, i_, images, W, H, samples, threads=4))
+                    for name in ("none", "lists, stored depth"):
+                        for key in ("tri", "depth", "bgra"):
+                            assert np.array_equal(got[name][key], got["lists"][key]), (mesh_name, k, v, name, key)
+            used = devices["lists"].draw_counts()["chunk_list_draws"] - before
+            assert (used > 0) == has_lists, (mesh_name, used)
+            assert devices["none"].draw_counts()["chunk_list_draws"] == 0
+            for m in mesh.values():
+                m.destroy()
     finally:
         for d in devices.values():
             d.close()

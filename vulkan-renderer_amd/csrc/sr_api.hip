@@ -97,6 +97,7 @@ struct sr_device_t {
     uint32_t cull_epoch = 0;
     uint32_t cull_min_chunks = 8;                  // meshes of fewer chunks are not worth the extra launch (SR_CULL_MIN_CHUNKS)
     bool cull_enabled = true;                      // SR_NO_CULL=1 turns it off
+    bool chunk_vertex_lists = true;                 // meshes get chunk vertex lists for batches of views (SR_NO_CHUNK_VERTS=1: none)
     bool recompute_depth = true;                    // lean draws of view batches store no depth plane (SR_STORE_DEPTH=1: always store it)
     // Pairs of maps of the same size whose red channels have been packed into one chain for the shading pass (the reference's metallic and
     // roughness maps: eight texel loads per pixel instead of sixteen).  Made by the first sr_draw that uses the pair; gone with either map.
@@ -113,6 +114,8 @@ struct sr_mesh_t {
     uint32_t n_verts = 0, n_tris = 0;
     float4* d_chunk_sphere = nullptr;   // chunk culling: bounds of every chunk of setup_block_triangles() triangles ([chunks] spheres, then
     uint4* d_chunk_vrange = nullptr;    // [chunks] vertex ranges in the same allocation)
+    uint32_t* d_chunk_verts = nullptr;  // chunk vertex lists (one allocation: lists, counts, the triangles' list positions), or null:
+    ChunkVerts chunk_verts{};           // a chunk with too many or too widely spread vertices, or lists switched off
     uint32_t n_chunks = 0;
 };
 
@@ -428,9 +431,10 @@ int issue_draw(sr_device_t* dev, sr_target_t* tg)
         if (!fused) launch_vertex(st, m->px, m->py, m->pz, m->n_verts, d_views, nv, g.W, g.H, sp, nullptr, nullptr, dev->fill_blocks);
         if (ev) SR_HIP(hipEventRecord(ev[2], st));
         const DepthSource depth_source{m->px, m->py, m->pz, d_views};
+        if (pass == 0 && n_views >= 2 && m->d_chunk_verts) ++dev->counts.chunk_list_draws;
         launch_setup(st, m->d_idx, m->n_tris, sp, g, b, clip, nv, tg->d_vis, tg->flags, v0, ev ? ev[3] : nullptr, !tg->lean, dev->fill_blocks,
                      fused ? cull_use.visible : nullptr /* (culled vertex groups were skipped by the fused vertex launch only) */, dev->staged_min_blocks,
-                     depth_plane ? nullptr : &depth_source);
+                     depth_plane ? nullptr : &depth_source, m->d_chunk_verts ? &m->chunk_verts : nullptr);
         if (ev && !m->n_tris) SR_HIP(hipEventRecord(ev[3], st));
         if (ev) SR_HIP(hipEventRecord(ev[4], st));
         uint32_t* pass_counters = (uint32_t*)tg->hd_counters + (size_t)pass * kCountersPerPass;
@@ -583,6 +587,7 @@ int sr_device_create(int hip_ordinal, sr_device* out)
     if (const char* v = std::getenv("SR_FILL_BLOCKS")) dev->fill_blocks = (uint32_t)std::max(1, std::atoi(v));   // tests: 1 = a workgroup always takes all views
     if (const char* v = std::getenv("SR_CULL_MIN_CHUNKS")) dev->cull_min_chunks = (uint32_t)std::max(1, std::atoi(v));   // tests: cull small meshes too
     if (std::getenv("SR_NO_CULL")) dev->cull_enabled = false;
+    if (const char* v = std::getenv("SR_NO_CHUNK_VERTS")) dev->chunk_vertex_lists = std::atoi(v) == 0;
     if (const char* v = std::getenv("SR_STORE_DEPTH")) dev->recompute_depth = std::atoi(v) == 0;
     if (const char* v = std::getenv("SR_NO_PACKED_MAPS")) dev->pack_pairs = std::atoi(v) == 0;
     if (const char* v = std::getenv("SR_DIRECT_MAX_TRIANGLES")) dev->direct_max_triangles = (uint32_t)std::max(0, std::atoi(v));
@@ -655,8 +660,26 @@ int sr_mesh_create(sr_device dev, const void* vertices, uint32_t n_vertices, con
             launch_chunk_bounds(dev->stream, m->d_idx, n_tris, m->d_aos, m->d_chunk_sphere, m->d_chunk_vrange);
         }
     }
+    uint32_t* d_unfit = nullptr;
+    if (e == hipSuccess && n_tris && dev->chunk_vertex_lists) {   // the chunks' distinct vertices, for batches of views
+        const size_t list_words = (size_t)m->n_chunks * kChunkVertsMax, words = list_words + m->n_chunks + n_tris + 1;
+        e = hipMalloc((void**)&m->d_chunk_verts, words * 4);
+        if (e == hipSuccess) {
+            uint32_t* count = m->d_chunk_verts + list_words;
+            uint32_t* local = count + m->n_chunks;
+            d_unfit = local + n_tris;
+            m->chunk_verts = ChunkVerts{m->d_chunk_verts, count, local};
+            e = hipMemsetAsync(d_unfit, 0, 4, dev->stream);
+            if (e == hipSuccess) launch_chunk_verts(dev->stream, m->d_idx, n_tris, m->d_chunk_vrange, m->d_chunk_verts, count, local, d_unfit);
+        }
+    }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);   // uploaded on return, like the reference's blocking staging copy
+    if (e == hipSuccess && d_unfit) {
+        uint32_t unfit = 0;
+        e = hipMemcpy(&unfit, d_unfit, 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && unfit) { (void)hipFree(m->d_chunk_verts); m->d_chunk_verts = nullptr; m->chunk_verts = ChunkVerts{}; }
+    }
     if (e != hipSuccess) { (void)sr_mesh_destroy(dev, m); SR_HIP(e); }
     *out = m;
     return SR_OK;
@@ -671,6 +694,7 @@ int sr_mesh_destroy(sr_device dev, sr_mesh mesh)
         (void)hipStreamSynchronize(dev->stream);
     }
     (void)hipFree(mesh->d_aos); (void)hipFree(mesh->px); (void)hipFree(mesh->d_idx); (void)hipFree(mesh->d_chunk_sphere);
+    (void)hipFree(mesh->d_chunk_verts);
     delete mesh;
     return SR_OK;
 }

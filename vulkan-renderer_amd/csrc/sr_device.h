@@ -253,6 +253,21 @@ struct CullUse {
     uint32_t epoch;
 };
 
+// Chunk vertex lists ------------------------------------------------------------------------------
+// Made once per mesh: for every chunk of setup_block_triangles() consecutive triangles the distinct vertices it uses (ascending vertex
+// numbers) and, per triangle, where its three vertices stand in that list.  A set-up workgroup that goes through many views of a pass
+// then loads its chunk's window-space vertices of a view ONCE, side by side, into LDS, and its triangles take their vertices from
+// there: a strip of a grid mesh uses about one vertex per triangle, so a third of the bytes cross the L1 that three gathers per
+// triangle take -- and the L1 is what bounds that kernel.  A mesh with a chunk of more than kChunkVertsMax distinct vertices, or whose
+// vertex numbers inside a chunk span more than kChunkVertsSpan, has no lists and keeps the gathers.
+constexpr uint32_t kChunkVertsMax = 1024;         // distinct vertices of a chunk (three 10-bit list positions per triangle)
+constexpr uint32_t kChunkVertsSpan = 1u << 16;    // highest minus lowest vertex number of a chunk, plus one: a bitmap in LDS when the lists are made
+struct ChunkVerts {
+    const uint32_t* list;    // [chunks][kChunkVertsMax]: vertex numbers, ascending; `count[chunk]` of them are valid.  Null: the mesh has no lists
+    const uint32_t* count;   // [chunks]
+    const uint32_t* local;   // [triangles]: list positions of the three vertices, 10 bits each (vertex 0 lowest)
+};
+
 // binning records ---------------------------------------------------------------------------------
 struct BinRecord {            // 12 bytes, written by set-up, read by fill
     uint32_t tri;             // triangle id

@@ -407,13 +407,17 @@ __device__ inline T plane_at(const T* plane, uint32_t byte_offset)
 // ZCALC: the pass has no depth plane (a lean draw of a batch of views: the plane is a third of what the vertex stage writes, and only the
 // triangles that reach phase two -- a few in a hundred of a mesh much finer than the frame -- ever read it); phase two works the three
 // depths out again from the positions, with the vertex stage's own operations.
-template <int S, bool VIEW_LOOP, bool STAGED, bool ZCALC = false>
+// LOCAL (view loop, a mesh with chunk vertex lists -- sr_device.h): for every view the workgroup first loads the window-space x, y of its
+// chunk's distinct vertices into LDS, side by side, and the triangles take their vertices from there.  A queued triangle carries its three
+// list positions; phase two, which runs for entries of earlier views too, looks the vertex numbers up in the list and gathers as before.
+template <int S, bool VIEW_LOOP, bool STAGED, bool ZCALC = false, bool LOCAL = false>
 __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, ScreenPlanes sp,
                                                     FrameGeom g, BinBuffers b, ClipList clip, unsigned long long* __restrict__ vis, BlockFlags flags,
                                                     uint32_t view0, uint32_t n_views, uint32_t views_per_block, const uint32_t* __restrict__ chunk_visible,
-                                                    DepthSource ds)
+                                                    DepthSource ds, ChunkVerts cv)
 {
     static_assert(!ZCALC || !STAGED, "depths are worked out again in the form of phase two that resolves inside the walk");
+    static_assert(!LOCAL || VIEW_LOOP, "the chunk's vertices are kept in LDS by the workgroups that go through many views");
     // The queue of phase two.  One view per workgroup: filled in phase one, a barrier, emptied in phase two.  In the view loop a view of
     // a mesh much finer than the frame queues a few dozen triangles per workgroup -- half a wave's worth, and phase two would run for
     // them at half a wave's width once per view.  So the queue is kept over the views (every entry carries its view) and emptied when
@@ -423,7 +427,10 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     // wave has passed the next barrier -- so all waves derive the same queue length from it, and where the next view's entries go.
     constexpr uint32_t kDrainAt = 512u;
     constexpr uint32_t kQueueCap = VIEW_LOOP ? kSetupBlockTris + kDrainAt : kSetupBlockTris;     // (a view queues kSetupBlockTris entries at most)
-    __shared__ uint32_t s_q_tri[kQueueCap], s_q_i0[kQueueCap], s_q_i1[kQueueCap], s_q_i2[kQueueCap];
+    constexpr uint32_t kQueueWide = LOCAL ? 1u : kQueueCap;      // (LOCAL: a queued triangle's three list positions share one word)
+    __shared__ uint32_t s_q_tri[kQueueCap], s_q_i0[kQueueCap], s_q_i1[kQueueWide], s_q_i2[kQueueWide];
+    constexpr uint32_t kLocalPer = kChunkVertsMax / 256u;        // vertices of the chunk's list per work-item
+    __shared__ int2 s_vxy[LOCAL ? kChunkVertsMax : 1u];            // LOCAL: window-space x, y of the chunk's vertices in the current view
     __shared__ uint32_t s_q_view[VIEW_LOOP ? kQueueCap : 1u];
     __shared__ uint32_t s_q_count[2];
     // Staged resolve (STAGED: one sample, one view per workgroup, a launch of thousands of workgroups).  An atomic minimum costs what
@@ -457,7 +464,22 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
         tri[k] = blk * kSetupBlockTris + k * 256u + tid;
         in_range[k] = tri[k] < n_tris;
         const uint32_t tt = in_range[k] ? tri[k] : 0u;
-        i0[k] = idx[3 * (size_t)tt] << 3; i1[k] = idx[3 * (size_t)tt + 1] << 3; i2[k] = idx[3 * (size_t)tt + 2] << 3;
+        if constexpr (LOCAL) {      // the same offsets, into s_vxy: list positions * 8
+            const uint32_t loc = in_range[k] ? cv.local[tt] : 0u;
+            i0[k] = (loc << 3) & 0x1FF8u; i1[k] = (loc >> 7) & 0x1FF8u; i2[k] = (loc >> 17) & 0x1FF8u;
+        } else {
+            i0[k] = idx[3 * (size_t)tt] << 3; i1[k] = idx[3 * (size_t)tt + 1] << 3; i2[k] = idx[3 * (size_t)tt + 2] << 3;
+        }
+    }
+    // LOCAL: the chunk's distinct vertices, kLocalPer per work-item, as offsets into a view's xy plane
+    uint32_t n_local = 0, voff[kLocalPer];
+    if constexpr (LOCAL) {
+        n_local = cv.count[blk];
+#pragma unroll
+        for (uint32_t j = 0; j < kLocalPer; ++j) {
+            const uint32_t v = j * 256u + tid;
+            voff[j] = (v < n_local ? cv.list[(size_t)blk * kChunkVertsMax + v] : 0u) << 3;
+        }
     }
     // the indices are loaded once for all the views the workgroup handles (every view of a pass, unless the mesh is small): a batch of
     // views streams the index list once instead of once per view
@@ -465,16 +487,50 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
     // 5 % on a one-view frame of 10 M triangles)
     const uint32_t view_end = VIEW_LOOP ? min(view_begin + views_per_block, n_views) : view_begin + 1u;
     if (tid < 2u) s_q_count[tid] = 0u;
+    // LOCAL: a view's vertices are loaded into registers (vnext) while the view before it is worked on, and copied to LDS at the start of
+    // their view: with the loads issued only then, every wave of the workgroup waited for them at the barrier that follows
+    // (50 M triangles x 16 views: set-up 20.5 ms; loaded a view ahead 13.1 ms; without the lists 15.9 ms).
+    int2 vnext[kLocalPer];
+    if constexpr (LOCAL) {
+#pragma unroll
+        for (uint32_t j = 0; j < kLocalPer; ++j)
+            vnext[j] = j * 256u + tid < n_local ? plane_at(sp.xy + (size_t)view_begin * sp.stride, voff[j]) : make_int2(0, 0);
+    }
     __syncthreads();
     uint32_t q_seen0 = 0, q_seen1 = 0, q_total = 0;   // the two counters as last read after a barrier; entries in the queue (the same in every wave)
     for (uint32_t view = view_begin; view < view_end; ++view) {
     const uint32_t qp = VIEW_LOOP ? (view - view_begin) & 1u : 0u;
     const int2* xy = sp.xy + (size_t)view * sp.stride;
     int2 r0[kSetupTris], r1[kSetupTris], r2[kSetupTris];
+    if constexpr (LOCAL) {
+        // (the previous view's readers of s_vxy are through: they passed that view's barrier after phase one)
 #pragma unroll
-    for (uint32_t k = 0; k < kSetupTris; ++k) {
-        SR_IN_LOOP(i0[k]); SR_IN_LOOP(i1[k]); SR_IN_LOOP(i2[k]);
-        r0[k] = plane_at(xy, i0[k]); r1[k] = plane_at(xy, i1[k]); r2[k] = plane_at(xy, i2[k]);
+        for (uint32_t j = 0; j < kLocalPer; ++j) {
+            const uint32_t v = j * 256u + tid;
+            if (v < n_local) s_vxy[v] = vnext[j];
+        }
+        __syncthreads();
+        if (view + 1u < view_end) {
+            const int2* xy_next = xy + sp.stride;
+#pragma unroll
+            for (uint32_t j = 0; j < kLocalPer; ++j) {
+                SR_IN_LOOP(voff[j]);
+                if (j * 256u + tid < n_local) vnext[j] = plane_at(xy_next, voff[j]);
+            }
+        }
+        const char* here = reinterpret_cast<const char*>(s_vxy);
+#pragma unroll
+        for (uint32_t k = 0; k < kSetupTris; ++k) {
+            r0[k] = *reinterpret_cast<const int2*>(here + i0[k]);
+            r1[k] = *reinterpret_cast<const int2*>(here + i1[k]);
+            r2[k] = *reinterpret_cast<const int2*>(here + i2[k]);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kSetupTris; ++k) {
+            SR_IN_LOOP(i0[k]); SR_IN_LOOP(i1[k]); SR_IN_LOOP(i2[k]);
+            r0[k] = plane_at(xy, i0[k]); r1[k] = plane_at(xy, i1[k]); r2[k] = plane_at(xy, i2[k]);
+        }
     }
 
     // Phase one: the cheap tests, for every triangle.  Micro-triangles whose box holds a sample point are queued in LDS (their id and
@@ -549,7 +605,9 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
         for (uint32_t k = 0; k < kSetupTris; ++k) {
             if (queued[k]) {
                 const uint32_t q = base + (uint32_t)__popcll(qm[k] & ((1ull << lane) - 1ull));
-                s_q_tri[q] = tri[k]; s_q_i0[q] = i0[k]; s_q_i1[q] = i1[k]; s_q_i2[q] = i2[k];
+                s_q_tri[q] = tri[k];
+                if constexpr (LOCAL) s_q_i0[q] = (i0[k] >> 3) | (i1[k] << 7) | (i2[k] << 17);     // (the three list positions again, 10 bits each)
+                else { s_q_i0[q] = i0[k]; s_q_i1[q] = i1[k]; s_q_i2[q] = i2[k]; }
                 if constexpr (VIEW_LOOP) s_q_view[q] = view;
             }
             base += (uint32_t)__popcll(qm[k]);
@@ -633,7 +691,12 @@ __global__ __launch_bounds__(256) SR_SETUP_ATTR void setup_kernel(const uint32_t
                 }
             } else
             if (q < n_q) {
-                const uint32_t t = s_q_tri[q], j0 = s_q_i0[q], j1 = s_q_i1[q], j2 = s_q_i2[q];
+                const uint32_t t = s_q_tri[q];
+                uint32_t j0 = s_q_i0[q], j1, j2;
+                if constexpr (LOCAL) {          // list positions -> vertex numbers -> offsets into a view's xy plane
+                    const uint32_t* mine = cv.list + (size_t)blk * kChunkVertsMax;
+                    j1 = mine[(j0 >> 10) & 1023u] << 3; j2 = mine[(j0 >> 20) & 1023u] << 3; j0 = mine[j0 & 1023u] << 3;
+                } else { j1 = s_q_i1[q]; j2 = s_q_i2[q]; }
                 const int2* xy_q = xy;
                 const float* zp_q = zp;
                 unsigned long long* vis_q = vis_view;
@@ -2072,6 +2135,75 @@ __global__ __launch_bounds__(256) void chunk_bounds_kernel(const uint32_t* __res
     }
 }
 
+// Chunk vertex lists (sr_device.h), one workgroup per chunk: a bitmap over the chunk's span of vertex numbers in LDS gives the distinct
+// vertices in ascending order (the same lists whatever order the work-items run in); a triangle's vertex then stands at the number of
+// set bits before its own.  A chunk that does not fit counts in `unfit` (the mesh then has no lists).
+__global__ __launch_bounds__(256) void chunk_verts_kernel(const uint32_t* __restrict__ idx, uint32_t n_tris, const uint4* __restrict__ vrange,
+                                                          uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t* __restrict__ local,
+                                                          uint32_t* __restrict__ unfit)
+{
+    constexpr uint32_t kWords = kChunkVertsSpan / 32u, kPer = kWords / 256u;     // words of the bitmap, and of one work-item's stretch of it
+    static_assert(kWords % 256u == 0u, "every work-item takes the same number of consecutive words");
+    static_assert(kChunkVertsMax <= 1024u, "three list positions share a 32-bit word");
+    __shared__ uint32_t s_bits[kWords], s_before[kWords];
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6, chunk = blockIdx.x, first = chunk * kChunkCullTris;
+    const uint4 r = vrange[chunk];
+    if (r.x > r.y || r.y - r.x >= kChunkVertsSpan) {      // (the same for the whole workgroup)
+        if (tid == 0) { count[chunk] = 0u; atomicAdd(unfit, 1u); }
+        return;
+    }
+    for (uint32_t w = tid; w < kWords; w += 256u) s_bits[w] = 0u;
+    __syncthreads();
+    uint32_t v[kSetupTris][3];
+    bool have[kSetupTris];
+#pragma unroll
+    for (uint32_t k = 0; k < kSetupTris; ++k) {
+        const uint32_t t = first + k * 256u + tid;
+        have[k] = t < n_tris;
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c) {
+            v[k][c] = have[k] ? idx[3 * (size_t)t + c] - r.x : 0u;
+            if (have[k]) atomicOr(&s_bits[v[k][c] >> 5], 1u << (v[k][c] & 31u));
+        }
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) mine += (uint32_t)__popc(s_bits[tid * kPer + j]);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if (lane >= (uint32_t)o) incl += u; }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (total > kChunkVertsMax) {                          // (the same for the whole workgroup)
+        if (tid == 0) { count[chunk] = 0u; atomicAdd(unfit, 1u); }
+        return;
+    }
+    for (uint32_t j = 0; j < kPer; ++j) {
+        const uint32_t word = tid * kPer + j;
+        s_before[word] = before;
+        for (uint32_t bits = s_bits[word]; bits != 0u; bits &= bits - 1u)
+            list[(size_t)chunk * kChunkVertsMax + before++] = r.x + word * 32u + (uint32_t)__ffs((int)bits) - 1u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kSetupTris; ++k) {
+        if (!have[k]) continue;
+        uint32_t packed = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c) {
+            const uint32_t word = v[k][c] >> 5;
+            packed |= (s_before[word] + (uint32_t)__popc(s_bits[word] & ((1u << (v[k][c] & 31u)) - 1u))) << (10u * c);
+        }
+        local[first + k * 256u + tid] = packed;
+    }
+    if (tid == 0) count[chunk] = total;
+}
+
 // One work-item per chunk.  With A = proj * view * model, every position p of the chunk has clip coordinate
 // A_r . (c, 1) + A_r[0..2] . (p - c), the second term at most radius * |A_r[0..2]| in size.  If w stays positive over the sphere,
 // x / w and y / w over it are bounded by the quotients of the ends, and the chunk's window coordinates by the viewport transform of
@@ -2247,15 +2379,20 @@ static inline uint32_t chunk_grid(const BinBuffers& b) { return std::min<uint32_
 
 void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const ScreenPlanes& sp, const FrameGeom& g,
                   const BinBuffers& b, const ClipList& clip, uint32_t n_views, uint64_t* vis, const BlockFlags& flags, uint32_t view0, hipEvent_t between,
-                  bool bin, uint32_t fill_blocks, const uint32_t* chunk_visible, uint32_t staged_min_blocks, const DepthSource* depth_source)
+                  bool bin, uint32_t fill_blocks, const uint32_t* chunk_visible, uint32_t staged_min_blocks, const DepthSource* depth_source, const ChunkVerts* chunk_verts)
 {
     if (!n_tris || !n_views) return;
+    const ChunkVerts cv = chunk_verts ? *chunk_verts : ChunkVerts{};
     if (depth_source) {   // no depth plane: the view-loop form, whatever the number of views per workgroup
         const uint32_t gx = div_up(n_tris, kSetupBlockTris);
         const uint32_t vpb = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((uint64_t)n_views * gx / std::max(fill_blocks, 1u)), 1u), n_views);
         const dim3 grid(gx, div_up(n_views, vpb));
-        if (g.samples == 1) setup_kernel<1, true, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, vpb, nullptr, *depth_source);
-        else setup_kernel<4, true, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, vpb, nullptr, *depth_source);
+        // (a workgroup with several views loads its chunk's vertices once per view, where the mesh has the lists for that)
+        const bool local = chunk_verts && vpb >= 2u;
+        if (local && g.samples == 1) setup_kernel<1, true, false, true, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, vpb, nullptr, *depth_source, cv);
+        else if (local) setup_kernel<4, true, false, true, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, vpb, nullptr, *depth_source, cv);
+        else if (g.samples == 1) setup_kernel<1, true, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, vpb, nullptr, *depth_source, cv);
+        else setup_kernel<4, true, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, vpb, nullptr, *depth_source, cv);
         if (between) (void)hipEventRecord(between, st);
         return;           // (such a pass is a lean one: no binning)
     }
@@ -2266,12 +2403,14 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
     if (views_per_block == 1) {
         // (the staged resolve where the launch is long enough to be bound by what it does, not by how long one workgroup takes)
         const bool staged = g.samples == 1 && (uint64_t)grid.x * grid.y >= staged_min_blocks;
-        if (staged) setup_kernel<1, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{});
-        else if (g.samples == 1) setup_kernel<1, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{});
-        else setup_kernel<4, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{});
+        if (staged) setup_kernel<1, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{}, cv);
+        else if (g.samples == 1) setup_kernel<1, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{}, cv);
+        else setup_kernel<4, false, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, 1u, chunk_visible, DepthSource{}, cv);
     } else {
-        if (g.samples == 1) setup_kernel<1, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr, DepthSource{});
-        else setup_kernel<4, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr, DepthSource{});
+        if (chunk_verts && g.samples == 1) setup_kernel<1, true, false, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr, DepthSource{}, cv);
+        else if (chunk_verts) setup_kernel<4, true, false, false, true><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr, DepthSource{}, cv);
+        else if (g.samples == 1) setup_kernel<1, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr, DepthSource{}, cv);
+        else setup_kernel<4, true, false><<<grid, 256, 0, st>>>(idx, n_tris, sp, g, b, clip, (unsigned long long*)vis, flags, view0, n_views, views_per_block, nullptr, DepthSource{}, cv);
     }
     if (between) (void)hipEventRecord(between, st);
     if (!bin) return;
@@ -2335,6 +2474,12 @@ void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, c
 {
     if (!n_tris) return;
     chunk_bounds_kernel<<<div_up(n_tris, kChunkCullTris), 256, 0, st>>>(idx, n_tris, (const float4*)verts_aos, sphere, vrange);
+}
+
+void launch_chunk_verts(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const uint4* vrange, uint32_t* list, uint32_t* count, uint32_t* local, uint32_t* unfit)
+{
+    if (!n_tris) return;
+    chunk_verts_kernel<<<div_up(n_tris, kChunkCullTris), 256, 0, st>>>(idx, n_tris, vrange, list, count, local, unfit);
 }
 
 void launch_chunk_cull(hipStream_t st, const ChunkCull& cc, const CullView& v, const FrameGeom& g)

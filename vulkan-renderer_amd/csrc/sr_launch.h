@@ -52,10 +52,14 @@ void launch_setup(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const Sc
                   hipEvent_t between /* recorded between set-up and binning, may be null */, bool bin = true /* false: set-up only */,
                   uint32_t fill_blocks = kFillBlocks, const uint32_t* chunk_visible = nullptr /* chunk culling: one-view draws only */,
                   uint32_t staged_min_blocks = kStagedResolveMinBlocks,
-                  const DepthSource* depth_source = nullptr /* set: sp.z is null, set-up works depths out itself; set-up only, no binning */);
+                  const DepthSource* depth_source = nullptr /* set: sp.z is null, set-up works depths out itself; set-up only, no binning */,
+                  const ChunkVerts* chunk_verts = nullptr /* set: the mesh's chunk vertex lists, for workgroups that take several views */);
 // chunk culling (sr_device.h): bounds of every chunk of setup_block_triangles() triangles, once per mesh; the per-draw test
 void launch_chunk_bounds(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const void* verts_aos, float4* sphere, uint4* vrange);
 void launch_chunk_cull(hipStream_t st, const ChunkCull& cc, const CullView& v, const FrameGeom& g);
+// chunk vertex lists (sr_device.h), once per mesh, after launch_chunk_bounds: list [chunks][kChunkVertsMax], count [chunks], local [triangles];
+// *unfit (zeroed by the caller) counts the chunks that do not fit
+void launch_chunk_verts(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const uint4* vrange, uint32_t* list, uint32_t* count, uint32_t* local, uint32_t* unfit);
 // near-plane clipping of the triangles set-up listed: cuts them and resolves the pieces into the visibility buffer.
 // Runs after launch_setup and before launch_scan (which reports the counters to the host).
 void launch_near_clip(hipStream_t st, const uint32_t* idx, uint32_t n_tris, const float* px, const float* py, const float* pz,

@@ -58,7 +58,7 @@ class DrawStats(C.Structure):
 
 
 class DrawCounts(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("draws", "lean_draws", "direct_draws", "lean_redraws", "overflow_redraws", "chunks_tested", "chunks_culled")]
+    _fields_ = [(n, C.c_uint64) for n in ("draws", "lean_draws", "direct_draws", "lean_redraws", "overflow_redraws", "chunks_tested", "chunks_culled", "chunk_list_draws")]
 
 
 class StageTimes(C.Structure):
